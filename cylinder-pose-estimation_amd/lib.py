@@ -1,0 +1,59 @@
+"""ctypes loader for libcpe_hip.so (C ABI: include/cpe.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'libcpe_hip.so')
+_lib = None
+
+
+class CpeError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j4']
+    if not verbose:
+        cmd.insert(1, '-s')
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_SIGS = {
+    'cpe_version': (C.c_int32, []),
+    'cpe_last_error_string': (C.c_char_p, []),
+    'cpe_preprocess_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+}
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise CpeError(f'{SO_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(the product path has no CPU fallback)')
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cpe_last_error_string().decode()
+        raise CpeError(f'{what} failed (rc={rc}): {msg}')
+
+
+def declared_symbols():
+    """names declared with CPE_API in include/cpe.h"""
+    import re
+    hdr = os.path.join(_HERE, '..', 'include', 'cpe.h')
+    txt = open(hdr).read()
+    return sorted(set(re.findall(r'CPE_API[^;(]*?\b(cpe_\w+)\s*\(', txt)))
