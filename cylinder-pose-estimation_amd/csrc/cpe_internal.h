@@ -17,6 +17,9 @@ void set_error(const char *fmt, ...);
         }                                        \
     } while (0)
 
+// clear any stale sticky error left by other users of the runtime (e.g. torch device probing)
+#define CPE_LAUNCH_BEGIN() (void)hipGetLastError()
+
 #define CPE_CHECK_LAUNCH(name)                                                      \
     do {                                                                            \
         hipError_t e_ = hipGetLastError();                                          \

@@ -1,0 +1,95 @@
+"""Host-side mirror of utils/fitSingleCylinder.m for a batch of stereo frames.
+
+    [pts3, cylT, fvals, meanError] = fitSingleCylinder(i, gridPtsPair, cylRadius, ..., stereoParams, draw)
+
+becomes fit_single_cylinder_batch(tables_left, tables_right, K1, K2, T_C2_C1, radius): all frames at
+once, everything resident on the GPU, one wavefront per frame (csrc/fit.hip)."""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import lib as _lib
+
+MAXP = _lib.MAXP
+SEL_CHOOSE_IDX, SEL_THRESHOLD, SEL_JOIN = 0, 1, 2
+
+
+@dataclass
+class GridTables:
+    """padded grid-point tables of n images: the reference's N x 4 [x y colIdx rowIdx] matrices"""
+    xy: torch.Tensor    # f64 [n, MAXP, 2]
+    id: torch.Tensor    # i32 [n, MAXP, 2]  (col, row)
+    cnt: torch.Tensor   # i32 [n]
+
+    @staticmethod
+    def from_lists(mats, device):
+        """mats: list of (N_i x 4) arrays [x y col row] (makePyGridPts.m:41)"""
+        import numpy as np
+        n = len(mats)
+        xy = np.zeros((n, MAXP, 2)); ids = np.zeros((n, MAXP, 2), np.int32); cnt = np.zeros(n, np.int32)
+        for i, m in enumerate(mats):
+            m = np.asarray(m, dtype=np.float64).reshape(-1, 4)
+            if len(m) > MAXP:
+                raise ValueError(f'table {i} has {len(m)} points > MAXP={MAXP}')
+            xy[i, :len(m)] = m[:, :2]; ids[i, :len(m)] = m[:, 2:4].astype(np.int32); cnt[i] = len(m)
+        return GridTables(torch.from_numpy(xy).to(device), torch.from_numpy(ids).to(device),
+                          torch.from_numpy(cnt).to(device))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev3(a, device, shape):
+    t = torch.as_tensor(a, dtype=torch.float64).reshape(shape).contiguous()
+    return t.to(device)
+
+
+def select_triangulate_batch(gp1: GridTables, gp2: GridTables, K1, K2, T21, selector=SEL_CHOOSE_IDX, patch=3, th=0.3):
+    """chooseIdx / triangulateWithThreshold / findGridCorrespondences + triangulate (fitSingleCylinder.m:10-17)"""
+    L = _lib.load()
+    dev = gp1.xy.device
+    n = gp1.cnt.shape[0]
+    K1 = _dev3(K1, dev, (9,)); K2 = _dev3(K2, dev, (9,)); T21 = _dev3(T21, dev, (16,))
+    ws_bytes = L.cpe_fit_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+    p1 = torch.zeros((n, MAXP, 2), dtype=torch.float64, device=dev); p2 = torch.zeros_like(p1)
+    idx = torch.zeros((n, MAXP, 2), dtype=torch.int32, device=dev)
+    X = torch.zeros((n, MAXP, 3), dtype=torch.float64, device=dev)
+    err = torch.zeros((n, MAXP), dtype=torch.float64, device=dev)
+    m = torch.zeros(n, dtype=torch.int32, device=dev); me = torch.zeros(n, dtype=torch.float64, device=dev)
+    flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    _lib.check(L.cpe_select_triangulate_batch(gp1.xy.data_ptr(), gp1.id.data_ptr(), gp1.cnt.data_ptr(),
+                                              gp2.xy.data_ptr(), gp2.id.data_ptr(), gp2.cnt.data_ptr(), n,
+                                              K1.data_ptr(), K2.data_ptr(), T21.data_ptr(), selector, patch, th,
+                                              ws.data_ptr(), ws_bytes, p1.data_ptr(), p2.data_ptr(), idx.data_ptr(),
+                                              X.data_ptr(), err.data_ptr(), m.data_ptr(), me.data_ptr(),
+                                              flags.data_ptr(), _stream()), 'cpe_select_triangulate_batch')
+    return dict(p1=p1, p2=p2, idx=idx, pts3=X, err=err, m=m, mean_err=me, flags=flags, _ws=ws)
+
+
+def fit_cylinder_batch(pts3, cnt, radius, tol_x=1e-5, tol_f=1e-5, max_iter=100000, max_fun_evals=100000):
+    """fitCylinderWPts3 + applyCylParamsPrior + cylParams2T (fitSingleCylinder.m:20-25)"""
+    L = _lib.load()
+    dev = pts3.device
+    n = cnt.shape[0]
+    raw = torch.zeros((n, 2, 6), dtype=torch.float64, device=dev); cyl = torch.zeros_like(raw)
+    T = torch.zeros((n, 4, 4), dtype=torch.float64, device=dev)
+    fv = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    it = torch.zeros((n, 2), dtype=torch.int32, device=dev); st = torch.zeros(n, dtype=torch.int32, device=dev)
+    prm = _lib.CpeFitParams(tol_x, tol_f, max_iter, max_fun_evals)
+    _lib.check(L.cpe_fit_cylinder_batch(pts3.data_ptr(), cnt.data_ptr(), n, float(radius), C.addressof(prm),
+                                        raw.data_ptr(), cyl.data_ptr(), T.data_ptr(), fv.data_ptr(), it.data_ptr(),
+                                        st.data_ptr(), _stream()), 'cpe_fit_cylinder_batch')
+    return dict(cyl_raw=raw, cyl=cyl, T=T, fvals=fv, iters=it, status=st)
+
+
+def fit_single_cylinder_batch(gp1: GridTables, gp2: GridTables, K1, K2, T21, radius, selector=SEL_CHOOSE_IDX,
+                              patch=3, th=0.3, **fit_kw):
+    """[pts3, cylT, fvals, meanError] = fitSingleCylinder(...) for every frame of the batch."""
+    sel = select_triangulate_batch(gp1, gp2, K1, K2, T21, selector, patch, th)
+    fit = fit_cylinder_batch(sel['pts3'], sel['m'], radius, **fit_kw)
+    out = dict(sel)
+    out.update(fit)
+    return out

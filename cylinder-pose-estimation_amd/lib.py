@@ -27,7 +27,19 @@ _SIGS = {
     'cpe_version': (C.c_int32, []),
     'cpe_last_error_string': (C.c_char_p, []),
     'cpe_preprocess_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'cpe_fit_workspace_bytes': (C.c_size_t, [C.c_int32]),
+    'cpe_select_triangulate_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 +
+                                     [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
+    'cpe_fit_cylinder_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p] +
+                               [C.c_void_p] * 7),
 }
+
+
+class CpeFitParams(C.Structure):
+    _fields_ = [('tol_x', C.c_double), ('tol_f', C.c_double), ('max_iter', C.c_int32), ('max_fun_evals', C.c_int32)]
+
+
+MAXP = 1024
 
 
 def load():

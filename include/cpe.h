@@ -67,6 +67,58 @@ CPE_API const char *cpe_last_error_string(void);
 CPE_API int32_t cpe_preprocess_batch(const uint8_t *gray, int32_t n, int32_t h, int32_t w, uint8_t *mask,
                              void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Grid-point tables.  One table per image: xy f64[n,CPE_MAXP,2] pixel coordinates, id i32[n,CPE_MAXP,2]
+ * (col,row) grid indices, cnt i32[n] -- the padded form of the reference's N x 4 matrix
+ * [x y colIdx rowIdx] (makePyGridPts.m:39-41, pointsStruct2mat.m:16).
+ */
+#define CPE_MAXP 1024          /* capacity of one grid-point table */
+#define CPE_FIT_TABLE_DIM 128  /* (col,row) indices of one frame must span < 128 in each direction */
+
+#define CPE_FIT_FLAG_FALLBACK 1 /* selector found nothing -> plain index join (chooseIdx.m:101-104) */
+#define CPE_FIT_FLAG_OVERFLOW 2 /* index span exceeds CPE_FIT_TABLE_DIM or |index| > 9999: frame skipped */
+
+#define CPE_SEL_CHOOSE_IDX 0     /* chooseIdx(gp1,gp2,.,.,patch,th)          fitSingleCylinder.m:12 (live) */
+#define CPE_SEL_THRESHOLD 1      /* triangulateWithThreshold(gp1,gp2,.,.,th) fitSingleCylinder.m:11 */
+#define CPE_SEL_JOIN 2           /* findGridCorrespondences(gp1,gp2)         fitSingleCylinder.m:10 */
+
+CPE_API size_t cpe_fit_workspace_bytes(int32_t n);
+
+/* Index matching + triangulation for n stereo frames (one wavefront per frame).
+ * Replaces chooseIdx.m / triangulateWithThreshold.m / findGridCorrespondences.m followed by
+ * triangulate(cgp1, cgp2, stereoParams) at fitSingleCylinder.m:12-17.
+ *   K1, K2   f64[9]  row-major intrinsics (getCamParams.m:6-7), T21 f64[16] row-major T_C2_C1 (:9)
+ *   outputs  p1,p2 f64[n,CPE_MAXP,2] selected pixel pairs; idx i32[n,CPE_MAXP,2]; X f64[n,CPE_MAXP,3]
+ *            points in the camera-1 frame; err f64[n,CPE_MAXP] per-point reprojection error;
+ *            m i32[n] number of selected points; mean_err f64[n]; flags i32[n] (CPE_FIT_FLAG_*)
+ *   ws       cpe_fit_workspace_bytes(n) bytes of device scratch
+ */
+CPE_API int32_t cpe_select_triangulate_batch(const double *xy1, const int32_t *id1, const int32_t *cnt1,
+                                             const double *xy2, const int32_t *id2, const int32_t *cnt2, int32_t n,
+                                             const double *K1, const double *K2, const double *T21, int32_t selector,
+                                             int32_t patch, double th, void *ws, size_t ws_bytes, double *p1,
+                                             double *p2, int32_t *idx, double *X, double *err, int32_t *m,
+                                             double *mean_err, int32_t *flags, void *stream);
+
+typedef struct CpeFitParams {
+    double tol_x;          /* fminsearch TolX  (fitCylinderWPts3.m:33: 1e-5) */
+    double tol_f;          /* fminsearch TolFun (1e-5) */
+    int32_t max_iter;      /* MaxIter (1e5) */
+    int32_t max_fun_evals; /* MaxFunEvals (1e5) */
+} CpeFitParams;
+
+/* fitCylinderWPts3(pts3, radius) + applyCylParamsPrior + cylParams2T for n frames, one wavefront per
+ * frame (fitSingleCylinder.m:20-25).  X f64[n,CPE_MAXP,3], cnt i32[n].  params NULL = reference values.
+ *   cyl_raw f64[n,2,6]  [cylParams0; cylParams] as returned by fitCylinderWPts3
+ *   cyl     f64[n,2,6]  the same after applyCylParamsPrior
+ *   T       f64[n,16]   row-major cylT = cylParams2T(cyl(2,:))
+ *   fvals   f64[n,2]    [f0, f]        iters i32[n,2] = [iterations, function evaluations]
+ *   status  i32[n]      CPE_ST_OK or CPE_ST_FEW_POINTS
+ */
+CPE_API int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, int32_t n, double radius,
+                                       const CpeFitParams *params, double *cyl_raw, double *cyl, double *T,
+                                       double *fvals, int32_t *iters, int32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,3 +84,88 @@ def preprocess(gray, want_b=False):
     lib().orc_preprocess(_p(gray, C.c_uint8), h, w, _p(blurred, C.c_uint8), _p(mask, C.c_uint8),
                          _p(b, C.c_double) if want_b else None)
     return (blurred, mask, b) if want_b else (blurred, mask)
+
+
+# ---------------------------------------------------------------- geometric half (MATLAB side)
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def triangulate(p1, p2, K1, K2, T21):
+    """[ext] MATLAB triangulate: (n,2),(n,2) -> X (n,3) in camera-1 frame, per-point reprojection error"""
+    p1 = _f64(p1); p2 = _f64(p2); n = p1.shape[0]
+    X = np.empty((n, 3)); err = np.empty(n)
+    K1 = _f64(K1); K2 = _f64(K2); T21 = _f64(T21)
+    lib().orc_triangulate(_p(p1, C.c_double), _p(p2, C.c_double), n, _p(K1, C.c_double), _p(K2, C.c_double),
+                          _p(T21, C.c_double), _p(X, C.c_double), _p(err, C.c_double))
+    return X, err
+
+
+def choose_idx(gp1, gp2, K1, K2, T21, patch=3, th=0.3):
+    """chooseIdx.m -> (cgp1 (m,2), cgp2 (m,2), idx (m,2) int, used_fallback)"""
+    gp1 = _f64(gp1); gp2 = _f64(gp2); cap = max(len(gp1), len(gp2)) + 1
+    c1 = np.empty((cap, 2)); c2 = np.empty((cap, 2)); idx = np.empty((cap, 2), np.int32)
+    fb = C.c_int(0)
+    K1 = _f64(K1); K2 = _f64(K2); T21 = _f64(T21)
+    m = lib().orc_choose_idx(_p(gp1, C.c_double), len(gp1), _p(gp2, C.c_double), len(gp2), _p(K1, C.c_double),
+                             _p(K2, C.c_double), _p(T21, C.c_double), patch, C.c_double(th), _p(c1, C.c_double),
+                             _p(c2, C.c_double), _p(idx, C.c_int), C.byref(fb))
+    return c1[:m].copy(), c2[:m].copy(), idx[:m].copy(), bool(fb.value)
+
+
+def find_correspondences(gp1, gp2):
+    gp1 = _f64(gp1); gp2 = _f64(gp2); cap = len(gp1) + 1
+    c1 = np.empty((cap, 2)); c2 = np.empty((cap, 2)); idx = np.empty((cap, 2), np.int32)
+    m = lib().orc_find_correspondences(_p(gp1, C.c_double), len(gp1), _p(gp2, C.c_double), len(gp2),
+                                       _p(c1, C.c_double), _p(c2, C.c_double), _p(idx, C.c_int))
+    return c1[:m].copy(), c2[:m].copy(), idx[:m].copy()
+
+
+def dist_pts3_to_line(P, p1, p2):
+    """getDistPts3ToLine.m (P is (n,3))"""
+    P = _f64(P); d = np.empty(len(P)); p1 = _f64(p1); p2 = _f64(p2)
+    lib().orc_dist_pts3_to_line(_p(P, C.c_double), len(P), _p(p1, C.c_double), _p(p2, C.c_double), _p(d, C.c_double))
+    return d
+
+
+def cyl_objective(x, P, R):
+    lib().orc_cyl_objective.restype = C.c_double
+    x = _f64(x); P = _f64(P)
+    return lib().orc_cyl_objective(_p(x, C.c_double), _p(P, C.c_double), len(P), C.c_double(R))
+
+
+def fit_cylinder(P, R, tolx=1e-5, tolf=1e-5, maxiter=100000, maxfun=100000):
+    """fitCylinderWPts3.m: P (n,3) -> dict(cyl0[6], cyl[6], fvals[2], iters, evals, status)"""
+    P = _f64(P)
+    cyl0 = np.empty(6); cyl = np.empty(6); fv = np.empty(2); it = C.c_int(0); ev = C.c_int(0)
+    st = lib().orc_fit_cylinder(_p(P, C.c_double), len(P), C.c_double(R), C.c_double(tolx), C.c_double(tolf),
+                                maxiter, maxfun, _p(cyl0, C.c_double), _p(cyl, C.c_double), _p(fv, C.c_double),
+                                C.byref(it), C.byref(ev))
+    return dict(cyl0=cyl0, cyl=cyl, fvals=fv, iters=it.value, evals=ev.value, status=st)
+
+
+def apply_prior(cyl, P):
+    cyl = _f64(cyl).copy(); P = _f64(P)
+    lib().orc_apply_prior(_p(cyl, C.c_double), _p(P, C.c_double), len(P))
+    return cyl
+
+
+def cyl2T(cyl):
+    cyl = _f64(cyl); T = np.empty((4, 4))
+    lib().orc_cyl2T(_p(cyl, C.c_double), _p(T, C.c_double))
+    return T
+
+
+def fit_single_cylinder(gp1, gp2, K1, K2, T21, R, selector=0, th=0.3):
+    """fitSingleCylinder.m -> dict(pts3 (m,3), cyl (2,6), T (4,4), fvals, mean_err, iters, evals, status, fallback)"""
+    gp1 = _f64(gp1); gp2 = _f64(gp2); cap = max(len(gp1), len(gp2)) + 1
+    pts3 = np.empty((cap, 3)); cyl = np.zeros((2, 6)); T = np.zeros((4, 4)); fv = np.zeros(2)
+    m = C.c_int(0); me = C.c_double(0); it = C.c_int(0); ev = C.c_int(0); fb = C.c_int(0)
+    K1 = _f64(K1); K2 = _f64(K2); T21 = _f64(T21)
+    st = lib().orc_fit_single_cylinder(_p(gp1, C.c_double), len(gp1), _p(gp2, C.c_double), len(gp2),
+                                       _p(K1, C.c_double), _p(K2, C.c_double), _p(T21, C.c_double), C.c_double(R),
+                                       selector, C.c_double(th), _p(pts3, C.c_double), C.byref(m),
+                                       _p(cyl, C.c_double), _p(T, C.c_double), _p(fv, C.c_double), C.byref(me),
+                                       C.byref(it), C.byref(ev), C.byref(fb))
+    return dict(pts3=pts3[:m.value].copy(), cyl=cyl, T=T, fvals=fv, mean_err=me.value, iters=it.value,
+                evals=ev.value, status=st, fallback=bool(fb.value))

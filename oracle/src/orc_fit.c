@@ -1,0 +1,671 @@
+/*
+ * ORACLE (test infrastructure) -- the geometric half of the hot path:
+ *   utils/fitSingleCylinder.m:5-25, chooseIdx.m:19-104, findGridCorrespondences.m,
+ *   triangulateWithThreshold.m:16-43, fitCylinderWPts3.m, getDistPts3ToLine.m, estCurvatures.m,
+ *   fitplane.m, applyCylParamsPrior.m, cylParams2T.m, projPts3.m
+ *
+ * [ext] (MATLAB toolbox code absent from /root/reference; restated from its published behaviour,
+ * SURVEY.md appendix B -- PARITY UNPINNED, no MATLAB/Octave in this image):
+ *   triangulate  : per point 4x4 DLT, right singular vector of the smallest singular value
+ *                  (one-sided Jacobi SVD here), error = mean over the two views of the pixel distance
+ *   pca / eig    : cyclic Jacobi on the 3x3 covariance
+ *   knnsearch    : brute force, ties by index, self included
+ *   A\b          : 5x5 normal equations, Gaussian elimination with partial pivoting
+ *   fminsearch   : Lagarias et al. Nelder-Mead exactly as MATLAB's fminsearch.m orders it
+ *
+ * Documented deviation (SURVEY.md section 7 hard-part 6): estCurvatures takes eig's FIRST principal
+ * direction, which depends on the LAPACK sign of fitplane's normal; here the principal direction
+ * of smallest |curvature| is taken (the cylinder axis), independent of that sign.
+ *
+ * Every reduction over the points of a frame uses the fixed 64-lane tree `sum64` (lane l adds
+ * elements l, l+64, ... in order, then xor-butterfly 32..1), which is what one CDNA wavefront
+ * executes -- so the HIP kernels reproduce these numbers bit for bit.
+ */
+#include "orc_common.h"
+#include <float.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------ reductions */
+static double sum64(const double *v, int n)
+{
+    double p[64];
+    for (int l = 0; l < 64; l++) {
+        double a = 0.0;
+        for (int k = l; k < n; k += 64) a = a + v[k];
+        p[l] = a;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        double q[64];
+        for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof(p));
+    }
+    return p[0];
+}
+
+/* ------------------------------------------------------------------ triangulate [ext] */
+static void mat34_from_K_Rt(const double *K, const double *T, double *P) /* P = K * T(1:3,:) */
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) {
+            double s = 0.0;
+            for (int k = 0; k < 3; k++) s = s + K[r * 3 + k] * T[k * 4 + c];
+            P[r * 4 + c] = s;
+        }
+}
+
+/* one-sided Jacobi SVD of a 4x4: returns the right singular vector of the smallest singular value */
+static void svd4_null(const double *Ain, double *x)
+{
+    double U[16], V[16];
+    memcpy(U, Ain, sizeof(U));
+    for (int i = 0; i < 16; i++) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int k = 0; k < 4; k++) {
+                    al = al + U[k * 4 + p] * U[k * 4 + p];
+                    be = be + U[k * 4 + q] * U[k * 4 + q];
+                    ga = ga + U[k * 4 + p] * U[k * 4 + q];
+                }
+                if (fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+                rotated = 1;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                if (zeta < 0) t = -t;
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 4; k++) {
+                    double up = U[k * 4 + p], uq = U[k * 4 + q];
+                    U[k * 4 + p] = c * up - s * uq;
+                    U[k * 4 + q] = s * up + c * uq;
+                    double vp = V[k * 4 + p], vq = V[k * 4 + q];
+                    V[k * 4 + p] = c * vp - s * vq;
+                    V[k * 4 + q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int jm = 0;
+    double best = 0;
+    for (int j = 0; j < 4; j++) {
+        double nn = 0.0;
+        for (int k = 0; k < 4; k++) nn = nn + U[k * 4 + j] * U[k * 4 + j];
+        if (j == 0 || nn < best) { best = nn; jm = j; }
+    }
+    for (int k = 0; k < 4; k++) x[k] = V[k * 4 + jm];
+}
+
+static void project(const double *P, const double *X, double *u, double *v)
+{
+    double a = ((P[0] * X[0] + P[1] * X[1]) + P[2] * X[2]) + P[3];
+    double b = ((P[4] * X[0] + P[5] * X[1]) + P[6] * X[2]) + P[7];
+    double c = ((P[8] * X[0] + P[9] * X[1]) + P[10] * X[2]) + P[11];
+    *u = a / c;
+    *v = b / c;
+}
+
+/* triangulate(p1, p2, stereoParams): fitSingleCylinder.m:15, chooseIdx.m:57 */
+ORC_API void orc_triangulate(const double *p1, const double *p2, int n, const double *K1, const double *K2,
+                             const double *T21, double *X, double *err)
+{
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double P1[12], P2[12];
+    mat34_from_K_Rt(K1, I4, P1);
+    mat34_from_K_Rt(K2, T21, P2);
+    for (int i = 0; i < n; i++) {
+        double A[16], x[4];
+        for (int c = 0; c < 4; c++) {
+            A[0 * 4 + c] = p1[2 * i] * P1[8 + c] - P1[c];
+            A[1 * 4 + c] = p1[2 * i + 1] * P1[8 + c] - P1[4 + c];
+            A[2 * 4 + c] = p2[2 * i] * P2[8 + c] - P2[c];
+            A[3 * 4 + c] = p2[2 * i + 1] * P2[8 + c] - P2[4 + c];
+        }
+        svd4_null(A, x);
+        double Xi[3] = {x[0] / x[3], x[1] / x[3], x[2] / x[3]};
+        X[3 * i] = Xi[0]; X[3 * i + 1] = Xi[1]; X[3 * i + 2] = Xi[2];
+        double u, v, e1, e2, dx, dy;
+        project(P1, Xi, &u, &v);
+        dx = p1[2 * i] - u; dy = p1[2 * i + 1] - v;
+        e1 = sqrt(dx * dx + dy * dy);
+        project(P2, Xi, &u, &v);
+        dx = p2[2 * i] - u; dy = p2[2 * i + 1] - v;
+        e2 = sqrt(dx * dx + dy * dy);
+        err[i] = (e1 + e2) / 2.0;
+    }
+}
+
+/* ------------------------------------------------------------------ index selection */
+/* findGridCorrespondences.m: equi-join in gp1 order (first match in gp2) */
+ORC_API int orc_find_correspondences(const double *gp1, int n1, const double *gp2, int n2, double *c1,
+                                     double *c2, int *idx)
+{
+    int m = 0;
+    for (int i = 0; i < n1; i++) {
+        for (int j = 0; j < n2; j++)
+            if (gp2[4 * j + 2] == gp1[4 * i + 2] && gp2[4 * j + 3] == gp1[4 * i + 3]) {
+                c1[2 * m] = gp1[4 * i]; c1[2 * m + 1] = gp1[4 * i + 1];
+                c2[2 * m] = gp2[4 * j]; c2[2 * m + 1] = gp2[4 * j + 1];
+                if (idx) { idx[2 * m] = (int)gp1[4 * i + 2]; idx[2 * m + 1] = (int)gp1[4 * i + 3]; }
+                m++;
+                break;
+            }
+    }
+    return m;
+}
+
+static int find_row(const double *gp, int n, int c, int r)
+{
+    for (int i = 0; i < n; i++)
+        if ((int)gp[4 * i + 2] == c && (int)gp[4 * i + 3] == r) return i;
+    return -1;
+}
+
+/* containers.Map char keys 'c_r' sort as strings (chooseIdx.m:69,89) */
+static int key_cmp(const void *a, const void *b)
+{
+    const int *ka = (const int *)a, *kb = (const int *)b;
+    char sa[32], sb[32];
+    snprintf(sa, sizeof sa, "%d_%d", ka[0], ka[1]);
+    snprintf(sb, sizeof sb, "%d_%d", kb[0], kb[1]);
+    return strcmp(sa, sb);
+}
+
+static int int_cmp(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+static int uniq_sorted(const double *gp, int n, int col, int *out)
+{
+    int m = 0;
+    for (int i = 0; i < n; i++) out[m++] = (int)gp[4 * i + col];
+    qsort(out, m, sizeof(int), int_cmp);
+    int u = 0;
+    for (int i = 0; i < m; i++)
+        if (u == 0 || out[i] != out[u - 1]) out[u++] = out[i];
+    return u;
+}
+
+/* chooseIdx(gp1, gp2, ., stereoParams, patchSize, error_th): returns count; *fallback set when the
+ * plain join was used (chooseIdx.m:101-104). idx (optional) receives the (col,row) of each output row. */
+ORC_API int orc_choose_idx(const double *gp1, int n1, const double *gp2, int n2, const double *K1,
+                           const double *K2, const double *T21, int patch, double th, double *c1,
+                           double *c2, int *idx, int *fallback)
+{
+    int *ux = (int *)malloc((size_t)(n1 + 1) * sizeof(int)), *uy = (int *)malloc((size_t)(n1 + 1) * sizeof(int));
+    int nx = uniq_sorted(gp1, n1, 2, ux), ny = uniq_sorted(gp1, n1, 3, uy);
+    /* map: key (c,r) -> (row in gp1, row in gp2, best error) */
+    int cap = n1 + 1, nk = 0;
+    int *keys = (int *)malloc((size_t)cap * 4 * sizeof(int)); /* c, r, loc1, loc2 */
+    double *kerr = (double *)malloc((size_t)cap * sizeof(double));
+    int np = patch * patch;
+    double *q1 = (double *)malloc((size_t)np * 2 * sizeof(double)), *q2 = (double *)malloc((size_t)np * 2 * sizeof(double));
+    double *X = (double *)malloc((size_t)np * 3 * sizeof(double)), *er = (double *)malloc((size_t)np * sizeof(double));
+    int *l1 = (int *)malloc((size_t)np * sizeof(int)), *l2 = (int *)malloc((size_t)np * sizeof(int));
+    int *cc = (int *)malloc((size_t)np * 2 * sizeof(int));
+    for (int ix = 0; ix + patch <= nx; ix++)
+        for (int iy = 0; iy + patch <= ny; iy++) {
+            int ok = 1, m = 0;
+            for (int a = 0; a < patch && ok; a++)
+                for (int b = 0; b < patch; b++) {
+                    int c = ux[ix + a], r = uy[iy + b];
+                    int i1 = find_row(gp1, n1, c, r), i2 = find_row(gp2, n2, c, r);
+                    if (i1 < 0 || i2 < 0) { ok = 0; break; }
+                    cc[2 * m] = c; cc[2 * m + 1] = r; l1[m] = i1; l2[m] = i2;
+                    q1[2 * m] = gp1[4 * i1]; q1[2 * m + 1] = gp1[4 * i1 + 1];
+                    q2[2 * m] = gp2[4 * i2]; q2[2 * m + 1] = gp2[4 * i2 + 1];
+                    m++;
+                }
+            if (!ok) continue;
+            orc_triangulate(q1, q2, np, K1, K2, T21, X, er);
+            double s = 0.0;
+            for (int k = 0; k < np; k++) s = s + er[k];
+            if (!(s / np < th)) continue;
+            for (int k = 0; k < np; k++) {
+                int f = -1;
+                for (int j = 0; j < nk; j++)
+                    if (keys[4 * j] == cc[2 * k] && keys[4 * j + 1] == cc[2 * k + 1]) { f = j; break; }
+                if (f < 0) {
+                    if (nk == cap) {
+                        cap *= 2;
+                        keys = (int *)realloc(keys, (size_t)cap * 4 * sizeof(int));
+                        kerr = (double *)realloc(kerr, (size_t)cap * sizeof(double));
+                    }
+                    keys[4 * nk] = cc[2 * k]; keys[4 * nk + 1] = cc[2 * k + 1];
+                    keys[4 * nk + 2] = l1[k]; keys[4 * nk + 3] = l2[k];
+                    kerr[nk] = er[k];
+                    nk++;
+                } else if (er[k] < kerr[f]) {
+                    kerr[f] = er[k]; keys[4 * f + 2] = l1[k]; keys[4 * f + 3] = l2[k];
+                }
+            }
+        }
+    int m;
+    if (nk == 0) {
+        *fallback = 1;
+        m = orc_find_correspondences(gp1, n1, gp2, n2, c1, c2, idx);
+    } else {
+        *fallback = 0;
+        qsort(keys, nk, 4 * sizeof(int), key_cmp);
+        for (int j = 0; j < nk; j++) {
+            int i1 = keys[4 * j + 2], i2 = keys[4 * j + 3];
+            c1[2 * j] = gp1[4 * i1]; c1[2 * j + 1] = gp1[4 * i1 + 1];
+            c2[2 * j] = gp2[4 * i2]; c2[2 * j + 1] = gp2[4 * i2 + 1];
+            if (idx) { idx[2 * j] = keys[4 * j]; idx[2 * j + 1] = keys[4 * j + 1]; }
+        }
+        m = nk;
+    }
+    free(ux); free(uy); free(keys); free(kerr); free(q1); free(q2); free(X); free(er); free(l1); free(l2); free(cc);
+    return m;
+}
+
+/* triangulateWithThreshold.m:16-43 */
+ORC_API int orc_triangulate_with_threshold(const double *gp1, int n1, const double *gp2, int n2,
+                                           const double *K1, const double *K2, const double *T21, double th,
+                                           double *c1, double *c2, int *idx, int *fallback)
+{
+    int m = orc_find_correspondences(gp1, n1, gp2, n2, c1, c2, idx);
+    *fallback = 0;
+    if (m == 0) return 0;
+    double *X = (double *)malloc((size_t)m * 3 * sizeof(double)), *er = (double *)malloc((size_t)m * sizeof(double));
+    orc_triangulate(c1, c2, m, K1, K2, T21, X, er);
+    int k = 0;
+    for (int i = 0; i < m; i++)
+        if (er[i] < th) {
+            c1[2 * k] = c1[2 * i]; c1[2 * k + 1] = c1[2 * i + 1];
+            c2[2 * k] = c2[2 * i]; c2[2 * k + 1] = c2[2 * i + 1];
+            if (idx) { idx[2 * k] = idx[2 * i]; idx[2 * k + 1] = idx[2 * i + 1]; }
+            k++;
+        }
+    free(X); free(er);
+    if (k == 0) {
+        *fallback = 1;
+        return orc_find_correspondences(gp1, n1, gp2, n2, c1, c2, idx);
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------ small dense algebra */
+/* cyclic Jacobi on a symmetric 3x3; eigenvalues ascending in w, eigenvectors in columns of V */
+static void eig3(const double *Ain, double *w, double *V)
+{
+    double A[9];
+    memcpy(A, Ain, sizeof(A));
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double apq = A[p * 3 + q];
+                if (fabs(apq) <= 1e-17 * (fabs(A[p * 3 + p]) + fabs(A[q * 3 + q]))) continue;
+                rotated = 1;
+                double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+                double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                if (theta < 0) t = -t;
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) { /* A <- A J */
+                    double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                    A[k * 3 + p] = c * akp - s * akq;
+                    A[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) { /* A <- J^T A */
+                    double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                    A[p * 3 + k] = c * apk - s * aqk;
+                    A[q * 3 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - s * vkq;
+                    V[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int o[3] = {0, 1, 2};
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2 - i; j++)
+            if (A[o[j + 1] * 4] < A[o[j] * 4]) { int t = o[j]; o[j] = o[j + 1]; o[j + 1] = t; }
+    double Vs[9];
+    for (int j = 0; j < 3; j++) {
+        w[j] = A[o[j] * 4];
+        for (int k = 0; k < 3; k++) Vs[k * 3 + j] = V[k * 3 + o[j]];
+    }
+    memcpy(V, Vs, sizeof(Vs));
+}
+
+/* getDistPts3ToLine.m: distance of P (n x 3, row i = point i) to the line p1 -> p2 */
+static void dist_to_line(const double *P, int n, const double *p1, const double *p2, double *d)
+{
+    double v[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    double nv2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    for (int i = 0; i < n; i++) {
+        const double *x = P + 3 * i;
+        double al = (((x[0] - p1[0]) * v[0] + (x[1] - p1[1]) * v[1]) + (x[2] - p1[2]) * v[2]) / nv2;
+        double e0 = x[0] - (p1[0] + v[0] * al), e1 = x[1] - (p1[1] + v[1] * al), e2 = x[2] - (p1[2] + v[2] * al);
+        d[i] = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+    }
+}
+
+ORC_API void orc_dist_pts3_to_line(const double *P, int n, const double *p1, const double *p2, double *d)
+{
+    dist_to_line(P, n, p1, p2, d);
+}
+
+/* dist() of fitCylinderWPts3.m:44-49: sum((d - R)^2) */
+static double cyl_objective(const double *x, const double *P, int n, double R, double *tmp)
+{
+    double p2[3] = {x[0] + x[3], x[1] + x[4], x[2] + x[5]};
+    dist_to_line(P, n, x, p2, tmp);
+    for (int i = 0; i < n; i++) {
+        double v = tmp[i] - R;
+        tmp[i] = v * v;
+    }
+    return sum64(tmp, n);
+}
+
+ORC_API double orc_cyl_objective(const double *x, const double *P, int n, double R)
+{
+    double *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
+    double f = cyl_objective(x, P, n, R, tmp);
+    free(tmp);
+    return f;
+}
+
+static double eps_of(double x) /* MATLAB eps(x) */
+{
+    x = fabs(x);
+    if (x < DBL_MIN) return 4.9406564584124654e-324;
+    int e;
+    frexp(x, &e); /* x = m * 2^e, m in [0.5,1) */
+    return ldexp(1.0, e - 53);
+}
+
+/* fminsearch clone (MATLAB fminsearch.m). n = 6. */
+static void nelder_mead6(const double *x0, const double *P, int n, double R, double tolx, double tolf,
+                         int maxiter, int maxfun, double *xout, double *fout, int *iters, int *evals)
+{
+    enum { N = 6 };
+    double v[N + 1][N], fv[N + 1];
+    double *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
+    memcpy(v[0], x0, sizeof(double) * N);
+    fv[0] = cyl_objective(v[0], P, n, R, tmp);
+    for (int j = 0; j < N; j++) {
+        memcpy(v[j + 1], x0, sizeof(double) * N);
+        if (v[j + 1][j] != 0) v[j + 1][j] = (1 + 0.05) * v[j + 1][j];
+        else v[j + 1][j] = 0.00025;
+        fv[j + 1] = cyl_objective(v[j + 1], P, n, R, tmp);
+    }
+    int func_evals = N + 1, itercount = 1;
+#define SORT_SIMPLEX()                                                             \
+    for (int a_ = 1; a_ <= N; a_++) { /* stable insertion sort ascending */        \
+        double fk = fv[a_], vk[N];                                                 \
+        memcpy(vk, v[a_], sizeof vk);                                              \
+        int b_ = a_ - 1;                                                           \
+        while (b_ >= 0 && fv[b_] > fk) {                                           \
+            fv[b_ + 1] = fv[b_];                                                   \
+            memcpy(v[b_ + 1], v[b_], sizeof vk);                                   \
+            b_--;                                                                  \
+        }                                                                          \
+        fv[b_ + 1] = fk;                                                           \
+        memcpy(v[b_ + 1], vk, sizeof vk);                                          \
+    }
+    SORT_SIMPLEX();
+    while (func_evals < maxfun && itercount < maxiter) {
+        double df = 0, dx = 0, vmax = v[0][0];
+        for (int j = 1; j <= N; j++) {
+            double a = fabs(fv[0] - fv[j]);
+            if (a > df) df = a;
+            for (int k = 0; k < N; k++) {
+                double b = fabs(v[j][k] - v[0][k]);
+                if (b > dx) dx = b;
+            }
+        }
+        for (int k = 1; k < N; k++)
+            if (v[0][k] > vmax) vmax = v[0][k];
+        double tf = 10 * eps_of(fv[0]), tx = 10 * eps_of(vmax);
+        if (df <= (tolf > tf ? tolf : tf) && dx <= (tolx > tx ? tolx : tx)) break;
+
+        double xbar[N], xr[N], xe[N], xc[N];
+        for (int k = 0; k < N; k++) {
+            double s = v[0][k];
+            for (int j = 1; j < N; j++) s = s + v[j][k];
+            xbar[k] = s / N;
+        }
+        for (int k = 0; k < N; k++) xr[k] = 2.0 * xbar[k] - 1.0 * v[N][k];
+        double fxr = cyl_objective(xr, P, n, R, tmp);
+        func_evals++;
+        int shrink = 0;
+        if (fxr < fv[0]) {
+            for (int k = 0; k < N; k++) xe[k] = 3.0 * xbar[k] - 2.0 * v[N][k];
+            double fxe = cyl_objective(xe, P, n, R, tmp);
+            func_evals++;
+            if (fxe < fxr) { memcpy(v[N], xe, sizeof xe); fv[N] = fxe; }
+            else { memcpy(v[N], xr, sizeof xr); fv[N] = fxr; }
+        } else if (fxr < fv[N - 1]) {
+            memcpy(v[N], xr, sizeof xr); fv[N] = fxr;
+        } else if (fxr < fv[N]) {
+            for (int k = 0; k < N; k++) xc[k] = 1.5 * xbar[k] - 0.5 * v[N][k];
+            double fxc = cyl_objective(xc, P, n, R, tmp);
+            func_evals++;
+            if (fxc <= fxr) { memcpy(v[N], xc, sizeof xc); fv[N] = fxc; }
+            else shrink = 1;
+        } else {
+            for (int k = 0; k < N; k++) xc[k] = 0.5 * xbar[k] + 0.5 * v[N][k];
+            double fxcc = cyl_objective(xc, P, n, R, tmp);
+            func_evals++;
+            if (fxcc < fv[N]) { memcpy(v[N], xc, sizeof xc); fv[N] = fxcc; }
+            else shrink = 1;
+        }
+        if (shrink) {
+            for (int j = 1; j <= N; j++) {
+                for (int k = 0; k < N; k++) v[j][k] = v[0][k] + 0.5 * (v[j][k] - v[0][k]);
+                fv[j] = cyl_objective(v[j], P, n, R, tmp);
+            }
+            func_evals += N;
+        }
+        SORT_SIMPLEX();
+        itercount++;
+    }
+#undef SORT_SIMPLEX
+    memcpy(xout, v[0], sizeof(double) * N);
+    *fout = fv[0];
+    *iters = itercount;
+    *evals = func_evals;
+    free(tmp);
+}
+
+/* solve M x = b (5x5), partial pivoting; M, b destroyed */
+static void solve5(double *M, double *b, double *x)
+{
+    enum { N = 5 };
+    for (int c = 0; c < N; c++) {
+        int pv = c;
+        for (int r = c + 1; r < N; r++)
+            if (fabs(M[r * N + c]) > fabs(M[pv * N + c])) pv = r;
+        if (pv != c) {
+            for (int k = 0; k < N; k++) { double t = M[c * N + k]; M[c * N + k] = M[pv * N + k]; M[pv * N + k] = t; }
+            double t = b[c]; b[c] = b[pv]; b[pv] = t;
+        }
+        for (int r = c + 1; r < N; r++) {
+            double f = M[r * N + c] / M[c * N + c];
+            for (int k = c; k < N; k++) M[r * N + k] = M[r * N + k] - f * M[c * N + k];
+            b[r] = b[r] - f * b[c];
+        }
+    }
+    for (int r = N - 1; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < N; k++) s = s - M[r * N + k] * x[k];
+        x[r] = s / M[r * N + r];
+    }
+}
+
+/* estCurvatures.m for ONE point i (only K(:,1,i) is consumed, fitCylinderWPts3.m:29):
+ * returns the principal direction of smallest |curvature| (documented deviation, see header) */
+static void est_curv_dir(const double *P, int n, int i, double *dir)
+{
+    int K = n < 20 ? n : 20;
+    int nb[20];
+    double *d2 = (double *)malloc((size_t)n * sizeof(double));
+    char *used = (char *)calloc((size_t)n, 1);
+    for (int j = 0; j < n; j++) {
+        double a = P[3 * j] - P[3 * i], b = P[3 * j + 1] - P[3 * i + 1], c = P[3 * j + 2] - P[3 * i + 2];
+        d2[j] = (a * a + b * b) + c * c;
+    }
+    for (int k = 0; k < K; k++) { /* knnsearch: ascending distance, ties by index */
+        int bj = -1;
+        for (int j = 0; j < n; j++)
+            if (!used[j] && (bj < 0 || d2[j] < d2[bj])) bj = j;
+        used[bj] = 1;
+        nb[k] = bj;
+    }
+    free(d2); free(used);
+    /* fitplane.m: cov -> eigenvector of the smallest eigenvalue */
+    double mu[3] = {0, 0, 0};
+    for (int k = 0; k < K; k++)
+        for (int c = 0; c < 3; c++) mu[c] = mu[c] + P[3 * nb[k] + c];
+    for (int c = 0; c < 3; c++) mu[c] = mu[c] / K;
+    double Cv[9] = {0};
+    for (int k = 0; k < K; k++) {
+        double e[3] = {P[3 * nb[k]] - mu[0], P[3 * nb[k] + 1] - mu[1], P[3 * nb[k] + 2] - mu[2]};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) Cv[a * 3 + b] = Cv[a * 3 + b] + e[a] * e[b];
+    }
+    for (int a = 0; a < 9; a++) Cv[a] = Cv[a] / (K - 1);
+    double w[3], V[9];
+    eig3(Cv, w, V);
+    double z[3] = {V[0], V[3], V[6]};
+    /* createLocCoordSys (estCurvatures.m:20-29) -- not normalised, as in the reference */
+    double x[3] = {1, 0, 0};
+    if (fabs(z[0]) > 0.9) { x[0] = 0; x[1] = 1; }
+    double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    double xx[3] = {y[1] * z[2] - y[2] * z[1], y[2] * z[0] - y[0] * z[2], y[0] * z[1] - y[1] * z[0]};
+    /* fitquadsurf (estCurvatures.m:31-38) */
+    double M[25] = {0}, rhs[5] = {0}, co[5];
+    for (int k = 0; k < K; k++) {
+        double e[3] = {P[3 * nb[k]] - mu[0], P[3 * nb[k] + 1] - mu[1], P[3 * nb[k] + 2] - mu[2]};
+        double lx = (e[0] * xx[0] + e[1] * xx[1]) + e[2] * xx[2];
+        double ly = (e[0] * y[0] + e[1] * y[1]) + e[2] * y[2];
+        double lz = (e[0] * z[0] + e[1] * z[1]) + e[2] * z[2];
+        double row[5] = {lx * lx, lx * ly, ly * ly, lx, ly};
+        for (int a = 0; a < 5; a++) {
+            for (int b = 0; b < 5; b++) M[a * 5 + b] = M[a * 5 + b] + row[a] * row[b];
+            rhs[a] = rhs[a] + row[a] * lz;
+        }
+    }
+    solve5(M, rhs, co);
+    /* eig([2a b; b 2c]) */
+    double a = co[0] * 2, b = co[1], c = co[2] * 2;
+    double hd = (a - c) / 2.0, mid = (a + c) / 2.0, rad = sqrt(hd * hd + b * b);
+    double l1 = mid - rad, l2 = mid + rad;
+    double lam = (fabs(l1) <= fabs(l2)) ? l1 : l2;
+    /* eigenvector of lam: (b, lam - a) or (lam - c, b) -- take the better conditioned */
+    double v0, v1;
+    if (fabs(lam - a) >= fabs(lam - c)) { v0 = b; v1 = lam - a; }
+    else { v0 = lam - c; v1 = b; }
+    double nn = sqrt(v0 * v0 + v1 * v1);
+    if (nn == 0) { v0 = 1; v1 = 0; nn = 1; }
+    v0 = v0 / nn; v1 = v1 / nn;
+    for (int k = 0; k < 3; k++) dir[k] = xx[k] * v0 + y[k] * v1;
+}
+
+/* fitCylinderWPts3(Pts3, cylRadius): P is n x 3 (row = point). returns 0 ok, 5 too few points */
+ORC_API int orc_fit_cylinder(const double *P, int n, double R, double tolx, double tolf, int maxiter,
+                             int maxfun, double *cyl0, double *cyl, double *fvals, int *iters, int *evals)
+{
+    if (n < 3) return 5;
+    double *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
+    double ctr[3];
+    for (int c = 0; c < 3; c++) {
+        for (int i = 0; i < n; i++) tmp[i] = P[3 * i + c];
+        ctr[c] = sum64(tmp, n) / n;
+    }
+    double Cv[9];
+    for (int a = 0; a < 3; a++)
+        for (int b = a; b < 3; b++) {
+            for (int i = 0; i < n; i++) tmp[i] = (P[3 * i + a] - ctr[a]) * (P[3 * i + b] - ctr[b]);
+            Cv[a * 3 + b] = Cv[b * 3 + a] = sum64(tmp, n) / (n - 1);
+        }
+    double w[3], V[9];
+    eig3(Cv, w, V);
+    double rdir[3] = {V[0], V[3], V[6]}; /* pca coeff(:,3): least variance */
+    if (rdir[2] < 0) { rdir[0] = -rdir[0]; rdir[1] = -rdir[1]; rdir[2] = -rdir[2]; }
+    double p2[3] = {ctr[0] + rdir[0], ctr[1] + rdir[1], ctr[2] + rdir[2]};
+    dist_to_line(P, n, ctr, p2, tmp);
+    int im = 0;
+    for (int i = 1; i < n; i++)
+        if (tmp[i] < tmp[im]) im = i;
+    double e0 = ctr[0] - P[3 * im], e1 = ctr[1] - P[3 * im + 1], e2 = ctr[2] - P[3 * im + 2];
+    double d2s = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+    double dir0[3];
+    est_curv_dir(P, n, im, dir0);
+    for (int c = 0; c < 3; c++) {
+        cyl0[c] = ctr[c] + rdir[c] * (R - d2s);
+        cyl0[3 + c] = dir0[c];
+    }
+    fvals[0] = cyl_objective(cyl0, P, n, R, tmp);
+    nelder_mead6(cyl0, P, n, R, tolx, tolf, maxiter, maxfun, cyl, &fvals[1], iters, evals);
+    free(tmp);
+    return 0;
+}
+
+/* applyCylParamsPrior.m */
+ORC_API void orc_apply_prior(double *cyl, const double *P, int n)
+{
+    double o[3] = {cyl[0], cyl[1], cyl[2]}, d[3] = {cyl[3], cyl[4], cyl[5]};
+    if (d[1] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+    double ymin = P[1];
+    for (int i = 1; i < n; i++)
+        if (P[3 * i + 1] < ymin) ymin = P[3 * i + 1];
+    double t = 0;
+    if (!(fabs(d[1]) < DBL_EPSILON)) t = (ymin - o[1]) / d[1];
+    for (int c = 0; c < 3; c++) { cyl[c] = o[c] + t * d[c]; cyl[3 + c] = d[c]; }
+}
+
+/* cylParams2T.m -> row-major 4x4 */
+ORC_API void orc_cyl2T(const double *cyl, double *T)
+{
+    double y[3] = {cyl[3], cyl[4], cyl[5]};
+    double ny = sqrt((y[0] * y[0] + y[1] * y[1]) + y[2] * y[2]);
+    for (int c = 0; c < 3; c++) y[c] = y[c] / ny;
+    double z[3] = {0 * y[2] - 0 * y[1], 0 * y[0] - 1 * y[2], 1 * y[1] - 0 * y[0]}; /* cross([1 0 0], y) */
+    double nz = sqrt((z[0] * z[0] + z[1] * z[1]) + z[2] * z[2]);
+    for (int c = 0; c < 3; c++) z[c] = z[c] / nz;
+    double x[3] = {y[1] * z[2] - y[2] * z[1], y[2] * z[0] - y[0] * z[2], y[0] * z[1] - y[1] * z[0]};
+    double nx = sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+    for (int c = 0; c < 3; c++) x[c] = x[c] / nx;
+    for (int r = 0; r < 3; r++) {
+        T[r * 4 + 0] = x[r]; T[r * 4 + 1] = y[r]; T[r * 4 + 2] = z[r]; T[r * 4 + 3] = cyl[r];
+    }
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+/* fitSingleCylinder.m:5-25.  selector: 0 = chooseIdx(3, th) [live], 1 = triangulateWithThreshold(th),
+ * 2 = findGridCorrespondences.  outputs: pts3 (m x 3), cyl (2 x 6, after applyCylParamsPrior), T (4x4),
+ * fvals[2], meanError.  returns status (0 ok, 5 too few points). *m_out = number of points. */
+ORC_API int orc_fit_single_cylinder(const double *gp1, int n1, const double *gp2, int n2, const double *K1,
+                                    const double *K2, const double *T21, double R, int selector, double th,
+                                    double *pts3, int *m_out, double *cyl, double *T, double *fvals,
+                                    double *mean_err, int *iters, int *evals, int *fallback)
+{
+    int cap = (n1 > n2 ? n1 : n2) + 1;
+    double *c1 = (double *)malloc((size_t)cap * 2 * sizeof(double)), *c2 = (double *)malloc((size_t)cap * 2 * sizeof(double));
+    int m;
+    *fallback = 0;
+    if (selector == 0) m = orc_choose_idx(gp1, n1, gp2, n2, K1, K2, T21, 3, th, c1, c2, NULL, fallback);
+    else if (selector == 1) m = orc_triangulate_with_threshold(gp1, n1, gp2, n2, K1, K2, T21, th, c1, c2, NULL, fallback);
+    else m = orc_find_correspondences(gp1, n1, gp2, n2, c1, c2, NULL);
+    *m_out = m;
+    int st = 5;
+    if (m > 0) {
+        double *er = (double *)malloc((size_t)m * sizeof(double));
+        orc_triangulate(c1, c2, m, K1, K2, T21, pts3, er);
+        *mean_err = sum64(er, m) / m;
+        free(er);
+        st = orc_fit_cylinder(pts3, m, R, 1e-5, 1e-5, 100000, 100000, cyl, cyl + 6, fvals, iters, evals);
+        if (st == 0) {
+            orc_apply_prior(cyl, pts3, m);
+            orc_apply_prior(cyl + 6, pts3, m);
+            orc_cyl2T(cyl + 6, T);
+        }
+    }
+    free(c1); free(c2);
+    return st;
+}
