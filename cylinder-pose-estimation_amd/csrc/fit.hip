@@ -590,6 +590,7 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
         double w[3], V[9];
         eig3(C2, w, V);
         double z[3] = {V[0], V[3], V[6]};
+        if (z[2] < 0) { z[0] = -z[0]; z[1] = -z[1]; z[2] = -z[2]; }  // normal away from the camera (documented)
         double x[3] = {1, 0, 0};
         if (fabs(z[0]) > 0.9) { x[0] = 0; x[1] = 1; }
         double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
@@ -611,8 +612,7 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
         solve5(M, rhs, co);
         double a = co[0] * 2, b = co[1], c = co[2] * 2;
         double hd = (a - c) / 2.0, mid = (a + c) / 2.0, rad = sqrt(hd * hd + b * b);
-        double l1 = mid - rad, l2 = mid + rad;
-        double lam = (fabs(l1) <= fabs(l2)) ? l1 : l2;
+        double lam = mid - rad;  // eig ascending: V(:,1)
         double v0, v1;
         if (fabs(lam - a) >= fabs(lam - c)) { v0 = b; v1 = lam - a; }
         else { v0 = lam - c; v1 = b; }

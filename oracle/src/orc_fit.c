@@ -14,8 +14,10 @@
  *   fminsearch   : Lagarias et al. Nelder-Mead exactly as MATLAB's fminsearch.m orders it
  *
  * Documented deviation (SURVEY.md section 7 hard-part 6): estCurvatures takes eig's FIRST principal
- * direction, which depends on the LAPACK sign of fitplane's normal; here the principal direction
- * of smallest |curvature| is taken (the cylinder axis), independent of that sign.
+ * direction, which depends on the LAPACK-determined sign of fitplane's normal V(:,1) (fitplane.m:13-14).
+ * That sign is not reproducible without MATLAB; here the normal is oriented away from the camera
+ * (z >= 0, the same assumption fitCylinderWPts3.m:13-19 makes for rdir) and eig's first (ascending)
+ * principal direction is then taken exactly as the reference does.
  *
  * Every reduction over the points of a frame uses the fixed 64-lane tree `sum64` (lane l adds
  * elements l, l+64, ... in order, then xor-butterfly 32..1), which is what one CDNA wavefront
@@ -498,7 +500,7 @@ static void solve5(double *M, double *b, double *x)
 }
 
 /* estCurvatures.m for ONE point i (only K(:,1,i) is consumed, fitCylinderWPts3.m:29):
- * returns the principal direction of smallest |curvature| (documented deviation, see header) */
+ * returns K(:,1,i), with the plane normal's sign fixed to z >= 0 (documented deviation, see header) */
 static void est_curv_dir(const double *P, int n, int i, double *dir)
 {
     int K = n < 20 ? n : 20;
@@ -532,6 +534,7 @@ static void est_curv_dir(const double *P, int n, int i, double *dir)
     double w[3], V[9];
     eig3(Cv, w, V);
     double z[3] = {V[0], V[3], V[6]};
+    if (z[2] < 0) { z[0] = -z[0]; z[1] = -z[1]; z[2] = -z[2]; } /* sign fixed like rdir (see header) */
     /* createLocCoordSys (estCurvatures.m:20-29) -- not normalised, as in the reference */
     double x[3] = {1, 0, 0};
     if (fabs(z[0]) > 0.9) { x[0] = 0; x[1] = 1; }
@@ -555,7 +558,8 @@ static void est_curv_dir(const double *P, int n, int i, double *dir)
     double a = co[0] * 2, b = co[1], c = co[2] * 2;
     double hd = (a - c) / 2.0, mid = (a + c) / 2.0, rad = sqrt(hd * hd + b * b);
     double l1 = mid - rad, l2 = mid + rad;
-    double lam = (fabs(l1) <= fabs(l2)) ? l1 : l2;
+    double lam = l1; /* eig ascending: V(:,1) (estCurvatures.m:13-14) */
+    (void)l2;
     /* eigenvector of lam: (b, lam - a) or (lam - c, b) -- take the better conditioned */
     double v0, v1;
     if (fabs(lam - a) >= fabs(lam - c)) { v0 = b; v1 = lam - a; }
