@@ -1,0 +1,136 @@
+/*
+ * ORACLE (test infrastructure) -- detect_grid end to end for one grey frame
+ *   python_grid_detection_cylinder.py:68-112 and util_cylinder.color_and_expand_lines (:2014-2060)
+ * Output: centre point + table (x, y, col, row) sorted by (col,row), i.e. what make_json serialises
+ * (util_cylinder.py:1674-1727) and makePyGridPts.m:39-41 decodes to an N x 4 matrix.
+ */
+#include "orc_common.h"
+
+#define ORC_MAXL 256
+#define ORC_MAXLP 256
+typedef struct {
+    int nlines;
+    int npts[ORC_MAXL];
+    double pts[ORC_MAXL][ORC_MAXLP][2];
+    double eq[ORC_MAXL][6];
+    int has_eq[ORC_MAXL];
+    int label[ORC_MAXL];
+} orc_lineset;
+
+void orc_preprocess(const uint8_t *gray, int h, int w, uint8_t *blurred, uint8_t *mask, double *b_out);
+int orc_extract_joints(const uint8_t *binary, int h, int w, uint8_t *hmask, uint8_t *vmask, int *cent, int cap);
+int orc_detect_largest_blob(const uint8_t *gray, int h, int w, double clip, uint8_t *mask, int *rect, uint8_t *cl_out,
+                            int *nkp_out);
+int orc_mask_roi_around_center(const uint8_t *hmask, const uint8_t *vmask, const uint8_t *mask_contour,
+                               const uint8_t *gray, int h, int w, uint8_t *roi_h, uint8_t *roi_v, int *r0, int *spot);
+void orc_expand_line_roi(const uint8_t *mask_roi, const uint8_t *mask_contour, int h, int w, int kernel_size,
+                         uint8_t *out, int *dbg);
+int orc_connected_components(const uint8_t *mask, int h, int w, int32_t *labels);
+void orc_blur7(const uint8_t *src, int h, int w, uint8_t *dst);
+void orc_group_points(const int *cent, int n, const int32_t *labels, int lh, int lw, int x_off, int y_off,
+                      orc_lineset *out);
+void orc_fit_lines(orc_lineset *ls, int is_row);
+void orc_remove_label(orc_lineset *rows, orc_lineset *cols);
+void orc_intersections(orc_lineset *rows, orc_lineset *cols, const int *rect);
+void orc_clean_and_relabel(orc_lineset *rows, orc_lineset *cols);
+int orc_index_points(const orc_lineset *rows, const orc_lineset *cols, const uint8_t *gauss7, int h, int w, int r0,
+                     double *center, double *xy, int *id, int cap);
+
+typedef struct {
+    /* optional intermediate images (h*w each) for stage-by-stage parity tests; any may be NULL */
+    uint8_t *binary, *hmask, *vmask, *mask_contour, *roi_h, *roi_v, *exp_h, *exp_v;
+    int *joints;      /* cap_joints x 2 : all joints (contour order) */
+    int cap_joints;
+    int n_joints;     /* out */
+    int n_cyl_joints; /* out: joints inside the bounding rect */
+    int rect[4];      /* out */
+    int r0;           /* out: circle_radius0 */
+    int spot[4];      /* out: ellipse cx, cy, a, b */
+    int n_rows, n_cols; /* out: lines after clean_and_relabel */
+    int n_keypoints;    /* out */
+} orc_detect_debug;
+
+/* returns status: 0 ok, 1 no region, 2 no spot, 3 no rows/cols, 4 empty */
+ORC_API int orc_detect_grid(const uint8_t *gray, int h, int w, double *center, double *xy, int *id, int cap,
+                            int *n_out, orc_detect_debug *dbg)
+{
+    size_t N = (size_t)h * w;
+    uint8_t *blurred = (uint8_t *)malloc(N), *binary = (uint8_t *)malloc(N);
+    uint8_t *hmask = (uint8_t *)malloc(N), *vmask = (uint8_t *)malloc(N), *mc = (uint8_t *)malloc(N);
+    uint8_t *roi_h = (uint8_t *)malloc(N), *roi_v = (uint8_t *)malloc(N);
+    uint8_t *exp_h = (uint8_t *)malloc(N), *exp_v = (uint8_t *)malloc(N), *g7 = (uint8_t *)malloc(N);
+    int capj = 1 << 16;
+    int *cent = (int *)malloc((size_t)capj * 2 * sizeof(int)), *cyl = (int *)malloc((size_t)capj * 2 * sizeof(int));
+    orc_lineset *rows = (orc_lineset *)malloc(sizeof(orc_lineset)), *cols = (orc_lineset *)malloc(sizeof(orc_lineset));
+    int32_t *lab_h = NULL, *lab_v = NULL;
+    uint8_t *crop = NULL;
+    int st = 0;
+    *n_out = 0;
+
+    /* 1 */ orc_preprocess(gray, h, w, blurred, binary, NULL);
+    /* 2 */ int nj = orc_extract_joints(binary, h, w, hmask, vmask, cent, capj);
+    if (nj > capj) nj = capj;
+    int rect[4] = {0, 0, 0, 0}, r0 = 0, spot[4] = {0, 0, 0, 0}, nkp = 0;
+    /* 3 */ st = orc_detect_largest_blob(gray, h, w, 4.5, mc, rect, NULL, &nkp);
+    int ncyl = 0;
+    if (st == 0) {
+        /* 4: keep joints inside boundingRect(max_contour) (half-open, :1918) */
+        for (int i = 0; i < nj; i++) {
+            int cx = cent[2 * i], cy = cent[2 * i + 1];
+            if (rect[0] <= cx && cx < rect[0] + rect[2] && rect[1] <= cy && cy < rect[1] + rect[3]) {
+                cyl[2 * ncyl] = cx; cyl[2 * ncyl + 1] = cy; ncyl++;
+            }
+        }
+        /* 5 */ st = orc_mask_roi_around_center(hmask, vmask, mc, gray, h, w, roi_h, roi_v, &r0, spot);
+    }
+    if (st == 0) {
+        /* 6 */
+        int ks = 91 + r0;
+        orc_expand_line_roi(roi_h, mc, h, w, ks, exp_h, NULL);
+        orc_expand_line_roi(roi_v, mc, h, w, ks, exp_v, NULL);
+        int x0 = rect[0], y0 = rect[1], cw = rect[2], ch = rect[3];
+        /* numpy slicing clips the crop at the image border */
+        if (x0 + cw > w) cw = w - x0;
+        if (y0 + ch > h) ch = h - y0;
+        crop = (uint8_t *)malloc((size_t)cw * ch);
+        lab_h = (int32_t *)malloc((size_t)cw * ch * sizeof(int32_t));
+        lab_v = (int32_t *)malloc((size_t)cw * ch * sizeof(int32_t));
+        for (int y = 0; y < ch; y++) memcpy(crop + (size_t)y * cw, exp_h + (size_t)(y0 + y) * w + x0, (size_t)cw);
+        orc_connected_components(crop, ch, cw, lab_h);
+        for (int y = 0; y < ch; y++) memcpy(crop + (size_t)y * cw, exp_v + (size_t)(y0 + y) * w + x0, (size_t)cw);
+        orc_connected_components(crop, ch, cw, lab_v);
+        orc_group_points(cyl, ncyl, lab_h, ch, cw, x0, y0, rows);
+        orc_group_points(cyl, ncyl, lab_v, ch, cw, x0, y0, cols);
+        orc_fit_lines(cols, 0);
+        orc_fit_lines(rows, 1);
+        orc_remove_label(rows, cols);
+        orc_intersections(rows, cols, rect);
+        orc_clean_and_relabel(rows, cols);
+        orc_blur7(gray, h, w, g7);
+        int n = orc_index_points(rows, cols, g7, h, w, r0, center, xy, id, cap);
+        if (n < 0) st = -n;
+        else *n_out = n;
+    }
+    if (dbg) {
+        if (dbg->binary) memcpy(dbg->binary, binary, N);
+        if (dbg->hmask) memcpy(dbg->hmask, hmask, N);
+        if (dbg->vmask) memcpy(dbg->vmask, vmask, N);
+        if (dbg->mask_contour) memcpy(dbg->mask_contour, mc, N);
+        if (dbg->roi_h && st != 1 && st != 2) memcpy(dbg->roi_h, roi_h, N);
+        if (dbg->roi_v && st != 1 && st != 2) memcpy(dbg->roi_v, roi_v, N);
+        if (dbg->exp_h && st != 1 && st != 2) memcpy(dbg->exp_h, exp_h, N);
+        if (dbg->exp_v && st != 1 && st != 2) memcpy(dbg->exp_v, exp_v, N);
+        if (dbg->joints) memcpy(dbg->joints, cent, (size_t)(nj < dbg->cap_joints ? nj : dbg->cap_joints) * 2 * sizeof(int));
+        dbg->n_joints = nj;
+        dbg->n_cyl_joints = ncyl;
+        memcpy(dbg->rect, rect, sizeof(rect));
+        dbg->r0 = r0;
+        memcpy(dbg->spot, spot, sizeof(spot));
+        dbg->n_rows = (st == 0 || st >= 3) ? rows->nlines : 0;
+        dbg->n_cols = (st == 0 || st >= 3) ? cols->nlines : 0;
+        dbg->n_keypoints = nkp;
+    }
+    free(blurred); free(binary); free(hmask); free(vmask); free(mc); free(roi_h); free(roi_v); free(exp_h); free(exp_v);
+    free(g7); free(cent); free(cyl); free(rows); free(cols); free(lab_h); free(lab_v); free(crop);
+    return st;
+}

@@ -15,3 +15,81 @@ def test_ridges_bit_identical_to_skimage(orc):
         emax, emin = orc.detect_ridges(z['img_' + k])
         assert np.array_equal(emin, z['emin_' + k]), k
         assert np.array_equal(emax, z['emax_' + k]), k
+
+
+def test_intersections_vs_scipy_hybr(orc):
+    """poly_intersection_solver (real scipy MINPACK hybr) vs the oracle's Newton restatement:
+    same accept/reject decision and solution within 1e-6 px (BASELINE: grid points within 1e-3 px)."""
+    from oracle import stages as S
+    d = json.load(open(os.path.join(GOLDEN, 'intersections.json')))
+    n_sol = 0; worst = 0.0; mism = []
+    for c in d['cases']:
+        got = S.poly_intersection(c['row'], c['col'])
+        want = c['sol']
+        if (got is None) != (want is None):
+            mism.append((c['row'], c['col'], got, want))
+            continue
+        if want is not None:
+            n_sol += 1
+            worst = max(worst, abs(got[0] - want[0]), abs(got[1] - want[1]))
+    assert not mism, f'{len(mism)} decision mismatches, first: {mism[0]}'
+    assert n_sol > 150
+    assert worst < 1e-6, worst
+
+
+def _labels_from(case, key, H, W):
+    lab = np.zeros((H - case['y_off'], W - case['x_off']), np.int32)
+    for x, y, v in case[key]:
+        lab[y, x] = v
+    return lab
+
+
+def test_topology_vs_reference(orc):
+    """group_points_by_label -> create_dummy_rows_cols -> fit_and_draw_polynomial(2) -> remove_label ->
+    find_and_assign_intersections_P -> clean_and_relabel, each step against the real functions' output."""
+    from oracle import stages as S
+    d = json.load(open(os.path.join(GOLDEN, 'topology.json')))
+    for case in d['cases']:
+        H, W = case['H'], case['W']
+        rows = S.group_points(case['centroids'], _labels_from(case, 'lab_h', H, W), case['x_off'], case['y_off'])
+        cols = S.group_points(case['centroids'], _labels_from(case, 'lab_v', H, W), case['x_off'], case['y_off'])
+        for ls, want in ((rows, case['grouped']['rows']), (cols, case['grouped']['cols'])):
+            assert ls.nlines == len(want)
+            for g, (lab, pts) in enumerate(want):
+                assert ls.label[g] == lab
+                assert [(int(a), int(b)) for a, b in ls.points()[g]] == [tuple(p) for p in pts]
+        S.fit_lines(cols, False); S.fit_lines(rows, True)
+        for ls, want, pre in ((rows, case['fitted']['rows'], 'row'), (cols, case['fitted']['cols'], 'col')):
+            for g in range(ls.nlines):
+                w_eq = want[f'{pre}{g + 1}']
+                np.testing.assert_allclose(ls.equations()[g], w_eq, rtol=1e-9, atol=1e-9)
+        S.remove_label(rows, cols)
+        assert rows.nlines == len(case['removed']['rows']) and cols.nlines == len(case['removed']['cols'])
+        for g in range(rows.nlines):
+            np.testing.assert_allclose(rows.equations()[g], case['removed']['rows_eq'][f'col{g + 1}'], rtol=1e-9, atol=1e-9)
+        for g in range(cols.nlines):
+            np.testing.assert_allclose(cols.equations()[g], case['removed']['cols_eq'][f'col{g + 1}'], rtol=1e-9, atol=1e-9)
+        S.intersections(rows, cols, (0, 0, W, H))
+        for ls, want in ((rows, case['inter']['rows']), (cols, case['inter']['cols'])):
+            for g in range(ls.nlines):
+                w_pts = want[f'col{g + 1}']
+                got = ls.points()[g]
+                assert len(got) == len(w_pts)
+                if w_pts:
+                    np.testing.assert_allclose(got, w_pts, rtol=0, atol=1e-6)
+        S.clean_and_relabel(rows, cols)
+        for ls, want, weq, pre in ((rows, case['clean']['rows'], case['clean']['rows_eq'], 'row'),
+                                   (cols, case['clean']['cols'], case['clean']['cols_eq'], 'col')):
+            assert ls.nlines == len(want)
+            for g in range(ls.nlines):
+                np.testing.assert_allclose(ls.points()[g], want[f'{pre}{g + 1}'], rtol=0, atol=1e-6)
+                np.testing.assert_allclose(ls.equations()[g], weq[f'{pre}{g + 1}'], rtol=1e-9, atol=1e-9)
+
+
+def test_pca_endpoints_vs_numpy_lapack(orc):
+    """get_pca_endpoints (np.cov + np.linalg.eig = LAPACK dgeev) vs the dlanv2 restatement."""
+    from oracle import stages as S
+    d = json.load(open(os.path.join(GOLDEN, 'pca_endpoints.json')))
+    for c in d['cases']:
+        p1, p2 = S.pca_endpoints(c['pts'])
+        assert list(map(float, p1)) == c['p1'] and list(map(float, p2)) == c['p2']
