@@ -1,0 +1,206 @@
+// Device-side building blocks shared by the image-stage kernels (gfx950).
+#pragma once
+#include "cpe_internal.h"
+
+namespace cpe {
+
+// ---------------------------------------------------------------- per-image state kept in the workspace
+constexpr int MAXROOTS = 32768;  // connected components considered per image and pass
+constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
+constexpr int MAXB = 4096;       // blobs per threshold
+constexpr int MAXG = 2048;       // blob groups (key-point candidates)
+constexpr int GCAP = 20;         // centres per group
+constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
+constexpr int MAXD = 262144;     // blob contour-distance scratch (double) per image and threshold
+constexpr int MAXL = 64;         // grid lines per direction
+constexpr int MAXLP = 64;        // points per grid line
+constexpr int MAXSEG = 2048;     // line fragments per mask in the expansion stage
+
+struct CompRec {        // one traced border
+    int root;           // start pixel (raster index) = discovery key
+    int is_hole;
+    long long a00, a10, a01;  // Green sums (exact integers)
+    int nverts;         // CHAIN_APPROX_SIMPLE vertex count
+    int npts;           // CHAIN_APPROX_NONE point count
+    int minx, maxx, miny, maxy;
+    int voff;           // offset of stored vertices (or -1)
+    int pad;
+};
+
+struct BlobRec { double x, y, r; int key; int pad; };
+struct Group { int n; int pad; double c[GCAP][3]; };
+
+struct FrameState {
+    int status;
+    int rect[4];        // boundingRect(max_contour)
+    int r0;             // circle_radius0
+    int spot[4];        // ellipse cx, cy, a, b
+    int n_roots;        // scratch counters (reset by the stage that uses them)
+    int n_comps;
+    int n_joints_all;   // all joints
+    int n_joints;       // joints inside rect (sorted in OpenCV contour order)
+    int n_blobs;
+    int n_groups;
+    int n_groups_prev;
+    int n_kp;
+    int n_verts;        // bump pointer of the vertex scratch
+    int n_dists;        // bump pointer of the distance scratch
+    int best_comp;      // index of the selected contour
+    int n_seg[2];       // valid fragments per mask (h, v)
+    float gang[2], glen[2];
+    int n_rows, n_cols;
+    int overflow;
+    int hull_n;
+    int pad[3];
+};
+
+struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
+
+// stage buffer bundles (all device pointers into the caller's workspace, plane-major [n][...])
+struct RegionBuffers {
+    uint8_t *cl, *ext, *mc, *touch;
+    int *lab, *roots;
+    unsigned int *hist;
+    uint8_t *lut;
+    BlobRec *blobs;
+    int *blob_d, *order;
+    double *dists;
+    Group *groups;
+    unsigned long long *best;
+    int *lohi, *hull;
+};
+struct MaskBuffers {
+    uint8_t *binary, *hmask, *vmask, *joints_mask, *tmpA, *tmpB, *g19, *cm, *mc, *roi_h, *roi_v, *base_h, *base_v, *exp_h,
+        *exp_v, *touch;
+    uint16_t *tmp16;
+    int *lab, *roots, *jtmp, *joints, *verts;
+    unsigned long long *best;
+    SegRec *segs;
+};
+
+// ---------------------------------------------------------------- union-find on an int label plane
+__device__ __forceinline__ int uf_load(const int *L, int i)
+{
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(const int *L, int x)
+{
+    int p;
+    while ((p = uf_load(L, x)) != x) x = p;
+    return x;
+}
+__device__ __forceinline__ void uf_unite(int *L, int a, int b)
+{
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// ---------------------------------------------------------------- Suzuki border following (OpenCV icvFetchContour)
+// Pred(x, y) -> bool : pixel is non-zero (false outside the image).
+// Visitor.point(x, y, is_vertex): every border pixel in order (CHAIN_APPROX_NONE); is_vertex marks the
+// subset CHAIN_APPROX_SIMPLE keeps.  Returns false if the step bound was hit.
+template <class Pred, class Visitor>
+__device__ bool trace_border(const Pred &nz, int x0, int y0, bool is_hole, Visitor &vis, int max_steps)
+{
+    const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int s, s_end;
+    s_end = s = is_hole ? 0 : 4;
+    int x1, y1;
+    do {
+        s = (s - 1) & 7;
+        x1 = x0 + DX[s];
+        y1 = y0 + DY[s];
+    } while (!nz(x1, y1) && s != s_end);
+    if (s == s_end) {
+        vis.point(x0, y0, true);
+        return true;
+    }
+    int x3 = x0, y3 = y0, prev_s = s ^ 4;
+    for (int step = 0; step < max_steps; step++) {
+        int x4, y4, k = 0;
+        for (;;) {
+            ++s;
+            x4 = x3 + DX[s & 7];
+            y4 = y3 + DY[s & 7];
+            if (nz(x4, y4) || ++k >= 16) break;
+        }
+        s &= 7;
+        bool vertex = (s != prev_s);
+        vis.point(x3, y3, vertex);
+        if (vertex) prev_s = s;
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return true;
+        x3 = x4;
+        y3 = y4;
+        s = (s + 4) & 7;
+    }
+    return false;
+}
+
+struct MaskPred {
+    const uint8_t *m;
+    int w, h;
+    __device__ __forceinline__ bool operator()(int x, int y) const
+    {
+        return x >= 0 && x < w && y >= 0 && y < h && m[(size_t)y * w + x] != 0;
+    }
+};
+struct ThreshPred {  // binarised = img > t
+    const uint8_t *m;
+    int w, h, t;
+    __device__ __forceinline__ bool operator()(int x, int y) const
+    {
+        return x >= 0 && x < w && y >= 0 && y < h && (int)m[(size_t)y * w + x] > t;
+    }
+};
+
+// Green sums + counts + bbox; optional vertex store
+struct StatVisitor {
+    long long a00 = 0, a10 = 0, a01 = 0;
+    int npts = 0, nverts = 0;
+    int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
+    bool have_prev = false;
+    int fx = 0, fy = 0, px = 0, py = 0;  // first and previous written point
+    __device__ __forceinline__ void edge(int x0, int y0, int x1, int y1)
+    {
+        long long dxy = (long long)x0 * y1 - (long long)x1 * y0;
+        a00 += dxy;
+        a10 += dxy * (x0 + x1);
+        a01 += dxy * (y0 + y1);
+    }
+    __device__ __forceinline__ void point(int x, int y, bool vertex)
+    {
+        npts++;
+        if (vertex) nverts++;
+        minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
+        if (have_prev) edge(px, py, x, y);
+        else { fx = x; fy = y; have_prev = true; }
+        px = x; py = y;
+    }
+    __device__ __forceinline__ void finish() { if (have_prev) edge(px, py, fx, fy); }
+};
+
+// cv2.moments(contour): m00, m10, m01 from the Green sums (contourMoments)
+__device__ __forceinline__ void moments_from_sums(long long a00, long long a10, long long a01, double &m00,
+                                                  double &m10, double &m01)
+{
+    m00 = m10 = m01 = 0;
+    double d00 = (double)a00;
+    if (fabs(d00) > 1.1920928955078125e-07) {
+        double db1_2, db1_6;
+        if (d00 > 0) { db1_2 = 0.5; db1_6 = 0.16666666666666666666666666666667; }
+        else { db1_2 = -0.5; db1_6 = -0.16666666666666666666666666666667; }
+        m00 = d00 * db1_2;
+        m10 = (double)a10 * db1_6;
+        m01 = (double)a01 * db1_6;
+    }
+}
+
+}  // namespace cpe

@@ -1,0 +1,163 @@
+// detect_grid for a batch of grey frames: orchestration of the image half of the hot path and its C ABI.
+//   reference: python_grid_detection_cylinder.py:68-112 (detect_grid) and
+//              util_cylinder.color_and_expand_lines (:2014-2060)
+// Stage order (the reference's 1..6, with independent stages hoisted):
+//   preprocess -> hmask/vmask/joints mask -> region (blob hull + rect) -> joints in rect, spot ellipse,
+//   roi masks, fragment expansion -> labels of the expanded masks -> blur7 -> lines / indexing kernel.
+// Everything stays in HBM between the u8 frame read and the point-table write; all scratch lives in the
+// caller-supplied workspace (cpe_detect_workspace_bytes), laid out plane-major so that every kernel
+// streams [n, h, w] planes with fully coalesced accesses.
+#include "cpe_dev.h"
+
+namespace cpe {
+
+int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
+int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
+int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
+int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
+int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *dst, hipStream_t s);
+size_t lines_ws_bytes();
+int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, int h, int w, const int *joints,
+                FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, hipStream_t s);
+
+namespace {
+
+struct Layout {
+    size_t off[40];
+    size_t bytes_per_frame[40];
+    size_t total;
+};
+
+enum Plane {
+    P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
+    P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_COUNT
+};
+
+Layout make_layout(int n, int h, int w)
+{
+    Layout L;
+    const size_t N = (size_t)h * w;
+    size_t per[P_COUNT];
+    for (int i = 0; i < P_COUNT; i++) per[i] = N;  // u8 planes by default
+    per[P_JOINTS] = (size_t)MAXJ * 2 * sizeof(int);
+    per[P_STATE] = sizeof(FrameState);
+    per[P_TMP16] = N * 2;
+    per[P_LAB0] = N * 4;
+    per[P_LAB1] = N * 4;
+    per[P_ROOTS] = (size_t)MAXROOTS * sizeof(int);
+    per[P_JTMP] = (size_t)MAXJ * 3 * sizeof(int);
+    per[P_VERTS] = (size_t)MAXV * 2 * sizeof(int);
+    per[P_BEST] = sizeof(unsigned long long);
+    per[P_SEGS] = (size_t)2 * MAXSEG * sizeof(SegRec);
+    per[P_HIST] = 16 * 256 * sizeof(unsigned int);
+    per[P_LUT] = 16 * 256;
+    per[P_BLOBS] = (size_t)MAXB * sizeof(BlobRec);
+    per[P_BLOB_D] = (size_t)MAXB * 2 * sizeof(int);
+    per[P_ORDER] = (size_t)MAXB * sizeof(int);
+    per[P_DISTS] = (size_t)MAXD * sizeof(double);
+    per[P_GROUPS] = (size_t)MAXG * sizeof(Group);
+    per[P_LOHI] = (size_t)2 * w * sizeof(int);
+    per[P_HULL] = (size_t)4 * w * sizeof(int);
+    per[P_LINES] = lines_ws_bytes();
+    size_t o = 0;
+    for (int i = 0; i < P_COUNT; i++) {
+        L.off[i] = o;
+        L.bytes_per_frame[i] = per[i];
+        o += align_up(per[i] * (size_t)n, 256);
+    }
+    L.total = o;
+    return L;
+}
+
+__global__ void k_state_init(FrameState *st, int n)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    FrameState z = {};
+    st[f] = z;
+}
+
+__global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    int s = st[f].status;
+    if (st[f].overflow) s = CPE_ST_OVERFLOW;
+    status[f] = s;
+    if (s != CPE_ST_OK) n_pts[f] = 0;
+}
+
+}  // namespace
+}  // namespace cpe
+
+using namespace cpe;
+
+extern "C" size_t cpe_detect_workspace_bytes(int32_t n, int32_t h, int32_t w)
+{
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return make_layout(n, h, w).total;
+}
+
+extern "C" int32_t cpe_detect_workspace_plane(int32_t n, int32_t h, int32_t w, int32_t plane, size_t *offset,
+                                              size_t *bytes_per_frame)
+{
+    CPE_CHECK_ARG(n > 0 && h > 0 && w > 0 && plane >= 0 && plane <= P_G7 && offset && bytes_per_frame,
+                  "cpe_detect_workspace_plane: bad argument");
+    Layout L = make_layout(n, h, w);
+    *offset = L.off[plane];
+    *bytes_per_frame = L.bytes_per_frame[plane];
+    return CPE_OK;
+}
+
+extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t h, int32_t w, void *ws, size_t ws_bytes,
+                                         double *xy, int32_t *id, int32_t *n_pts, double *center, int32_t *status,
+                                         void *stream)
+{
+    CPE_CHECK_ARG(gray && xy && id && n_pts && center && status, "cpe_detect_grid_batch: null pointer");
+    CPE_CHECK_ARG(n >= 0 && h >= 64 && w >= 64 && h <= 4096 && w <= 4096,
+                  "cpe_detect_grid_batch: need n>=0 and 64 <= h,w <= 4096 (got %d,%d,%d)", n, h, w);
+    if (n == 0) return CPE_OK;
+    Layout L = make_layout(n, h, w);
+    if (!ws || ws_bytes < L.total) {
+        cpe::set_error("cpe_detect_grid_batch: workspace too small (%zu < %zu)", ws_bytes, L.total);
+        return CPE_ERR_WORKSPACE;
+    }
+    CPE_CHECK_ARG(((uintptr_t)ws & 255) == 0, "cpe_detect_grid_batch: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *base = (uint8_t *)ws;
+#define PL(T, p) ((T *)(base + L.off[p]))
+    FrameState *st = PL(FrameState, P_STATE);
+    RegionBuffers R;
+    R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
+    R.lab = PL(int, P_LAB0); R.roots = PL(int, P_ROOTS); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
+    R.blobs = PL(BlobRec, P_BLOBS); R.blob_d = PL(int, P_BLOB_D); R.order = PL(int, P_ORDER); R.dists = PL(double, P_DISTS);
+    R.groups = PL(Group, P_GROUPS); R.best = PL(unsigned long long, P_BEST); R.lohi = PL(int, P_LOHI); R.hull = PL(int, P_HULL);
+    MaskBuffers M;
+    M.binary = PL(uint8_t, P_BINARY); M.hmask = PL(uint8_t, P_HMASK); M.vmask = PL(uint8_t, P_VMASK);
+    M.joints_mask = PL(uint8_t, P_JOINTS_MASK); M.tmpA = PL(uint8_t, P_TMPA); M.tmpB = PL(uint8_t, P_TMPB);
+    M.g19 = PL(uint8_t, P_G19); M.cm = PL(uint8_t, P_CM); M.mc = R.mc; M.roi_h = PL(uint8_t, P_ROI_H);
+    M.roi_v = PL(uint8_t, P_ROI_V); M.base_h = PL(uint8_t, P_BASE_H); M.base_v = PL(uint8_t, P_BASE_V);
+    M.exp_h = PL(uint8_t, P_EXP_H); M.exp_v = PL(uint8_t, P_EXP_V); M.touch = R.touch; M.tmp16 = PL(uint16_t, P_TMP16);
+    M.lab = R.lab; M.roots = R.roots; M.jtmp = PL(int, P_JTMP); M.joints = PL(int, P_JOINTS); M.verts = PL(int, P_VERTS);
+    M.best = R.best; M.segs = PL(SegRec, P_SEGS);
+    int rc;
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    CPE_CHECK_LAUNCH("k_state_init");
+    if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, stream)) != CPE_OK) return rc;
+    if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
+    if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
+    if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_label(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), s)) != CPE_OK) return rc;
+    if ((rc = ccl_label(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), s)) != CPE_OK) return rc;
+    if ((rc = blur7_u8(gray, n, h, w, M.tmp16, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
+    if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
+                          n_pts, center, s)) != CPE_OK)
+        return rc;
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);
+    CPE_CHECK_LAUNCH("k_finish");
+#undef PL
+    return CPE_OK;
+}

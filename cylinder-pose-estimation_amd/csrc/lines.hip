@@ -1,0 +1,417 @@
+// Stages a-7 .. a-14 on the GPU, one workgroup per image:
+//   label lookup of the joints (label_and_color_masks / group_points_by_label, util_cylinder.py:24-33, 376-394),
+//   create_dummy_rows_cols (:401-430), fit_and_draw_polynomial(2) (:473-550), remove_label (:1211-1269),
+//   find_and_assign_intersections_P / poly_intersection_solver (:1074-1151), clean_and_relabel (:1154-1206),
+//   indexing_data (:1350-1571), remove_minus_labels + make_json ordering (:1657-1727).
+// The arithmetic (operation order of the polynomial fit, the Newton iteration, the means) is the one
+// written in oracle/src/orc_lines.c, which is pinned against the real reference functions.
+// Lines live in per-image workspace slots; every re-ordering is an index list (no data movement).
+#include "cpe_dev.h"
+
+namespace cpe {
+
+struct LinesWS {
+    double gpts[2][MAXL][MAXLP][2];  // joints per line (rows = side 0, cols = side 1)
+    double ipts[2][MAXL][MAXLP][2];  // intersections per line
+    double eq[2][MAXL][6];
+    double ixy[MAXL][MAXL][2];
+    double key[2][MAXL];
+    double ent_xy[MAXL * MAXL][2];
+    int ent_id[MAXL * MAXL][2];
+    int gn[2][MAXL], in[2][MAXL], glabel[2][MAXL];
+    unsigned char ival[MAXL][MAXL];
+};
+
+size_t lines_ws_bytes() { return align_up(sizeof(LinesWS), 256); }
+
+namespace {
+
+__device__ __forceinline__ double polyval2(const double *c, double x) { return (c[0] * x + c[1]) * x + c[2]; }
+
+// np.polyfit(x, y, 2) as restated in the oracle: column-scaled Vandermonde + Householder QR
+__device__ void polyfit2(const double *x, const double *y, int n, double *coef)
+{
+    double A[MAXLP][3], b[MAXLP], scale[3], v[MAXLP];
+    for (int i = 0; i < n; i++) { A[i][0] = x[i] * x[i]; A[i][1] = x[i]; A[i][2] = 1.0; b[i] = y[i]; }
+    for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += A[i][c] * A[i][c];
+        scale[c] = sqrt(s);
+        for (int i = 0; i < n; i++) A[i][c] /= scale[c];
+    }
+    for (int c = 0; c < 3; c++) {
+        double nrm = 0;
+        for (int i = c; i < n; i++) nrm += A[i][c] * A[i][c];
+        nrm = sqrt(nrm);
+        double alpha = A[c][c] > 0 ? -nrm : nrm;
+        for (int i = c; i < n; i++) v[i] = A[i][c];
+        v[c] -= alpha;
+        double vn = 0;
+        for (int i = c; i < n; i++) vn += v[i] * v[i];
+        if (vn == 0) continue;
+        for (int k = c; k < 3; k++) {
+            double d = 0;
+            for (int i = c; i < n; i++) d += v[i] * A[i][k];
+            d = 2 * d / vn;
+            for (int i = c; i < n; i++) A[i][k] -= d * v[i];
+        }
+        double d = 0;
+        for (int i = c; i < n; i++) d += v[i] * b[i];
+        d = 2 * d / vn;
+        for (int i = c; i < n; i++) b[i] -= d * v[i];
+    }
+    double z[3];
+    for (int r = 2; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < 3; k++) s -= A[r][k] * z[k];
+        z[r] = s / A[r][r];
+    }
+    for (int c = 0; c < 3; c++) coef[c] = z[c] / scale[c];
+}
+
+// poly_intersection_solver restated (analytic Newton from the reference's start point)
+__device__ bool poly_intersection(const double *a, const double *b, double &xs, double &ys)
+{
+    double x_min = a[3], x_max = a[4], y_min = b[3], y_max = b[4];
+    double x = 0.5 * (x_min + x_max);
+    double y = polyval2(a, x);
+    bool ok = false;
+    for (int it = 0; it < 50; it++) {
+        double f1 = y - polyval2(a, x), f2 = x - polyval2(b, y);
+        double da = 2 * a[0] * x + a[1], db = 2 * b[0] * y + b[1];
+        double det = da * db - 1.0;
+        if (det == 0 || !isfinite(det)) break;
+        double dx = (-f1 * (-db) - 1.0 * (-f2)) / det;
+        double dy = ((-da) * (-f2) - 1.0 * (-f1)) / det;
+        x += dx; y += dy;
+        if (!isfinite(x) || !isfinite(y)) break;
+        double nd = sqrt(dx * dx + dy * dy), nx = sqrt(x * x + y * y);
+        if (nd <= 1.49012e-8 * nx || nd == 0) { ok = true; break; }
+    }
+    if (!ok) return false;
+    {
+        double f1 = y - polyval2(a, x), f2 = x - polyval2(b, y);
+        double da = 2 * a[0] * x + a[1], db = 2 * b[0] * y + b[1];
+        double det = da * db - 1.0;
+        if (det != 0 && isfinite(det)) {
+            x += (-f1 * (-db) - 1.0 * (-f2)) / det;
+            y += ((-da) * (-f2) - 1.0 * (-f1)) / det;
+        }
+    }
+    if ((x_min - 1e-3 <= x && x <= x_max + 1e-3) && (y_min - 1e-3 <= y && y <= y_max + 1e-3)) {
+        xs = x; ys = y;
+        return true;
+    }
+    return false;
+}
+
+// stable insertion sort of an index list by key (ascending)
+__device__ void sort_by_key(int *ord, int n, const double *key)
+{
+    for (int a = 1; a < n; a++) {
+        int o = ord[a];
+        int b = a - 1;
+        while (b >= 0 && key[ord[b]] > key[o]) { ord[b + 1] = ord[b]; b--; }
+        ord[b + 1] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, const int *__restrict__ lab_v,
+                                               const uint8_t *__restrict__ g7, int h, int w,
+                                               const int *__restrict__ joints, FrameState *__restrict__ st,
+                                               LinesWS *__restrict__ wsall, double *__restrict__ o_xy,
+                                               int *__restrict__ o_id, int *__restrict__ o_n, double *__restrict__ o_center)
+{
+    const int f = blockIdx.x, t = threadIdx.x;
+    FrameState &S = st[f];
+    __shared__ int s_ng[2], s_ord[2][MAXL], s_n[2], s_ovf;
+    __shared__ int s_pref[MAXL + 1];
+    __shared__ double s_rv[256];
+    __shared__ int s_ri[256];
+    __shared__ int s_crow, s_ccol, s_total, s_cq;
+    if (t == 0) { o_n[f] = 0; o_center[2 * f] = 0; o_center[2 * f + 1] = 0; }
+    if (S.status != CPE_ST_OK) return;
+    LinesWS &W = wsall[f];
+    const size_t N = (size_t)h * w;
+    const int *L[2] = {lab_h + f * N, lab_v + f * N};
+    const int *J = joints + (size_t)f * MAXJ * 2;
+    const int nj = min(S.n_joints, MAXJ);
+    if (t == 0) s_ovf = 0;
+    __syncthreads();
+
+    // group_points_by_label: groups in order of first appearance (threads 0 and 64: one side each)
+    if (t == 0 || t == 64) {
+        const int sd = t >> 6;
+        int ng = 0;
+        for (int i = 0; i < nj; i++) {
+            int jx = J[2 * i], jy = J[2 * i + 1];
+            if (jx < 0 || jx >= w || jy < 0 || jy >= h) continue;
+            int lab = L[sd][(size_t)jy * w + jx];
+            if (lab < 0) continue;
+            int g = -1;
+            for (int k = 0; k < ng; k++)
+                if (W.glabel[sd][k] == lab) { g = k; break; }
+            if (g < 0) {
+                if (ng == MAXL) { s_ovf = 1; continue; }
+                g = ng++;
+                W.glabel[sd][g] = lab;
+                W.gn[sd][g] = 0;
+            }
+            int q = W.gn[sd][g];
+            if (q < MAXLP) {
+                W.gpts[sd][g][q][0] = (double)jx;
+                W.gpts[sd][g][q][1] = (double)jy;
+                W.gn[sd][g] = q + 1;
+            } else s_ovf = 1;
+        }
+        s_ng[sd] = ng;
+    }
+    __syncthreads();
+    // sort_rows: stable by min y (rows AND cols), then create_dummy_rows_cols + fit (degree 2)
+    if (t < 128) {
+        const int sd = t >> 6, g = t & 63;
+        if (g < s_ng[sd]) {
+            const int n = W.gn[sd][g];
+            double m = W.gpts[sd][g][0][1];
+            for (int k = 1; k < n; k++) m = fmin(m, W.gpts[sd][g][k][1]);
+            W.key[sd][g] = m;
+            s_ord[sd][g] = g;
+            for (int k = 0; k < 6; k++) W.eq[sd][g][k] = 0;
+            if (n >= 3) {
+                double tt[MAXLP], uu[MAXLP];
+                int ord[MAXLP];
+                const int kc = sd == 0 ? 0 : 1;  // rows: y = f(x) sorted by x; cols: x = f(y) sorted by y
+                for (int i = 0; i < n; i++) ord[i] = i;
+                for (int a = 1; a < n; a++) {
+                    int o = ord[a];
+                    int b = a - 1;
+                    while (b >= 0 && W.gpts[sd][g][ord[b]][kc] > W.gpts[sd][g][o][kc]) { ord[b + 1] = ord[b]; b--; }
+                    ord[b + 1] = o;
+                }
+                for (int i = 0; i < n; i++) { tt[i] = W.gpts[sd][g][ord[i]][kc]; uu[i] = W.gpts[sd][g][ord[i]][1 - kc]; }
+                double c[3];
+                polyfit2(tt, uu, n, c);
+                double lo = tt[0] - 50, hi = tt[n - 1] + 50;
+                W.eq[sd][g][0] = c[0]; W.eq[sd][g][1] = c[1]; W.eq[sd][g][2] = c[2];
+                W.eq[sd][g][3] = lo; W.eq[sd][g][4] = hi; W.eq[sd][g][5] = fabs(hi - lo);
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0 || t == 64) {
+        const int sd = t >> 6;
+        sort_by_key(s_ord[sd], s_ng[sd], W.key[sd]);
+        // remove_label: first row, last col
+        int n = s_ng[sd];
+        if (sd == 0) {
+            if (n > 0) { for (int k = 0; k + 1 < n; k++) s_ord[0][k] = s_ord[0][k + 1]; n--; }
+        } else {
+            if (n > 0) n--;
+        }
+        s_n[sd] = n;
+    }
+    __syncthreads();
+    const int nr = s_n[0], nc = s_n[1];
+    // find_and_assign_intersections_P: all (row, col) pairs
+    const int *rect = S.rect;
+    for (int p = t; p < nr * nc; p += 256) {
+        int r = p / nc, c = p - r * nc;
+        double x, y;
+        bool ok = poly_intersection(W.eq[0][s_ord[0][r]], W.eq[1][s_ord[1][c]], x, y);
+        if (ok) ok = (rect[0] <= x && x <= rect[0] + rect[2]) && (rect[1] <= y && y <= rect[1] + rect[3]);
+        W.ival[r][c] = ok ? 1 : 0;
+        W.ixy[r][c][0] = x;
+        W.ixy[r][c][1] = y;
+    }
+    __syncthreads();
+    // per-line lists in loop order, and the clean_and_relabel keys (mean y for rows, mean x for cols)
+    if (t < 128) {
+        const int sd = t >> 6, pos = t & 63;
+        if (pos < s_n[sd]) {
+            const int slot = s_ord[sd][pos];
+            int k = 0;
+            double sum = 0;
+            const int other = sd == 0 ? nc : nr;
+            for (int q = 0; q < other; q++) {
+                int r = sd == 0 ? pos : q, c = sd == 0 ? q : pos;
+                if (!W.ival[r][c]) continue;
+                if (k < MAXLP) {
+                    W.ipts[sd][slot][k][0] = W.ixy[r][c][0];
+                    W.ipts[sd][slot][k][1] = W.ixy[r][c][1];
+                    sum += W.ixy[r][c][sd == 0 ? 1 : 0];
+                    k++;
+                }
+            }
+            W.in[sd][slot] = k;
+            W.key[sd][slot] = k > 0 ? sum / k : 0.0;
+        }
+    }
+    __syncthreads();
+    if (t == 0 || t == 64) {
+        const int sd = t >> 6;
+        int n = 0;
+        for (int k = 0; k < s_n[sd]; k++)
+            if (W.in[sd][s_ord[sd][k]] > 0) s_ord[sd][n++] = s_ord[sd][k];
+        sort_by_key(s_ord[sd], n, W.key[sd]);
+        s_n[sd] = n;
+    }
+    __syncthreads();
+    const int NR = s_n[0], NC = s_n[1];
+    if (t == 0) { S.n_rows = NR; S.n_cols = NC; }
+    if (NR == 0) {
+        if (t == 0) S.status = CPE_ST_NO_LINES;
+        return;
+    }
+    // ---- indexing_data: centre = first maximum of the blurred-window mean over the row points
+    if (t == 0) {
+        int acc = 0;
+        for (int r = 0; r < NR; r++) { s_pref[r] = acc; acc += W.in[0][s_ord[0][r]]; }
+        s_pref[NR] = acc;
+    }
+    __syncthreads();
+    const int PR = s_pref[NR];
+    int half = (int)(S.r0 / 5.0);
+    if (half < 3) half = 3;
+    if (half > 10) half = half + 5;
+    const uint8_t *G = g7 + f * N;
+    double bv = -1e300;
+    int bq = INT_MAX;
+    for (int q = t; q < PR; q += 256) {
+        int r = 0;
+        while (s_pref[r + 1] <= q) r++;
+        const double *p = W.ipts[0][s_ord[0][r]][q - s_pref[r]];
+        double x = p[0], y = p[1];
+        int xs = (int)(x - half), xe = (int)(x + half), ys = (int)(y - half), ye = (int)(y + half);
+        xs = max(xs, 0); xe = min(xe, w); ys = max(ys, 0); ye = min(ye, h);
+        long cnt = (long)(xe > xs ? xe - xs : 0) * (ye > ys ? ye - ys : 0);
+        double m = -1.0;
+        if (cnt > 0) {
+            unsigned long sum = 0;
+            for (int yy = ys; yy < ye; yy++)
+                for (int xx = xs; xx < xe; xx++) sum += G[(size_t)yy * w + xx];
+            m = (double)sum / (double)cnt;
+        }
+        if (m > bv) { bv = m; bq = q; }   // q increases per thread: keeps the first maximum
+    }
+    s_rv[t] = bv; s_ri[t] = bq;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off) {
+            double ov = s_rv[t + off]; int oi = s_ri[t + off];
+            if (ov > s_rv[t] || (ov == s_rv[t] && oi < s_ri[t])) { s_rv[t] = ov; s_ri[t] = oi; }
+        }
+        __syncthreads();
+    }
+    double cx, cy;
+    {
+        int q = s_ri[0], r = 0;
+        while (s_pref[r + 1] <= q) r++;
+        const double *p = W.ipts[0][s_ord[0][r]][q - s_pref[r]];
+        cx = p[0]; cy = p[1];
+    }
+    __syncthreads();
+    // centre row: first minimum distance over row points (in order); centre col: same over col points
+    for (int side = 0; side < 2; side++) {
+        double bd = 1e300;
+        int bi = INT_MAX;
+        const int nl = side == 0 ? NR : NC;
+        // flattened order index = (line position << 8) | point index  (MAXLP <= 256)
+        for (int ln = 0; ln < nl; ln++) {
+            const int slot = s_ord[side][ln];
+            const int np = W.in[side][slot];
+            for (int k = t; k < np; k += 256) {
+                double ddx = cx - W.ipts[side][slot][k][0], ddy = cy - W.ipts[side][slot][k][1];
+                double d = sqrt(ddx * ddx + ddy * ddy);
+                int qi = (ln << 8) | k;
+                if (d < bd || (d == bd && qi < bi)) { bd = d; bi = qi; }
+            }
+        }
+        s_rv[t] = bd; s_ri[t] = bi;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (t < off) {
+                double ov = s_rv[t + off]; int oi = s_ri[t + off];
+                if (ov < s_rv[t] || (ov == s_rv[t] && oi < s_ri[t])) { s_rv[t] = ov; s_ri[t] = oi; }
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            int v = s_ri[0] == INT_MAX ? -1 : (s_ri[0] >> 8);
+            if (side == 0) s_crow = v; else s_ccol = v;
+        }
+        __syncthreads();
+    }
+    const int crow = s_crow, ccol = s_ccol;
+    if (ccol < 0) {
+        if (t == 0) S.status = CPE_ST_NO_LINES;
+        return;
+    }
+    // cols_dict: every col point -> id (col - centre col, nearest row - centre row); keep col >= 0
+    if (t == 0) {
+        int acc = 0;
+        for (int c = 0; c < NC; c++) { s_pref[c] = acc; acc += (c >= ccol) ? W.in[1][s_ord[1][c]] : 0; }
+        s_pref[NC] = acc;
+        s_total = acc;
+    }
+    __syncthreads();
+    const int total = s_total;
+    if (total == 0) {
+        if (t == 0) S.status = CPE_ST_EMPTY;
+        return;
+    }
+    for (int e = t; e < total; e += 256) {
+        int c = 0;
+        while (s_pref[c + 1] <= e) c++;
+        const double *p = W.ipts[1][s_ord[1][c]][e - s_pref[c]];
+        double px = p[0], py = p[1];
+        int nrw = -1;
+        double mdd = INFINITY;
+        for (int r = 0; r < NR; r++) {
+            const int slot = s_ord[0][r];
+            const int np = W.in[0][slot];
+            for (int q = 0; q < np; q++) {
+                double ddx = px - W.ipts[0][slot][q][0], ddy = py - W.ipts[0][slot][q][1];
+                double d = sqrt(ddx * ddx + ddy * ddy);
+                if (d < mdd) { mdd = d; nrw = r; }
+            }
+        }
+        W.ent_xy[e][0] = px; W.ent_xy[e][1] = py;
+        W.ent_id[e][0] = c - ccol;
+        W.ent_id[e][1] = nrw >= 0 ? nrw - crow : 0;
+    }
+    __syncthreads();
+    // make_json: stable sort by (col,row)
+    const int nout = min(total, CPE_MAXP);
+    for (int e = t; e < total; e += 256) {
+        int kc = W.ent_id[e][0], kr = W.ent_id[e][1], rank = 0;
+        for (int j = 0; j < total; j++) {
+            int jc = W.ent_id[j][0], jr = W.ent_id[j][1];
+            bool less = jc < kc || (jc == kc && (jr < kr || (jr == kr && j < e)));
+            rank += less ? 1 : 0;
+        }
+        if (rank < CPE_MAXP) {
+            size_t o = (size_t)f * CPE_MAXP + rank;
+            o_xy[2 * o] = W.ent_xy[e][0]; o_xy[2 * o + 1] = W.ent_xy[e][1];
+            o_id[2 * o] = kc; o_id[2 * o + 1] = kr;
+        }
+    }
+    if (t == 0) {
+        o_n[f] = nout;
+        o_center[2 * f] = cx; o_center[2 * f + 1] = cy;
+        if (total > CPE_MAXP || s_ovf) S.overflow = 1;
+    }
+}
+
+}  // namespace
+
+int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, int h, int w, const int *joints,
+                FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, hipStream_t s)
+{
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
+                       o_id, o_n, o_center);
+    CPE_CHECK_LAUNCH("k_lines");
+    return CPE_OK;
+}
+
+}  // namespace cpe

@@ -1,0 +1,768 @@
+// Stages a-2, a-4, a-5, a-6 on the GPU:
+//   extract_joints (util_cylinder.py:1805-1827), the joint filter of find_cylinder_centroids_and_center
+//   (:1913-1920), mask_roi_around_center (:1944-2007), expands_line_roi / expand_line_roi /
+//   process_contour_info / create_rotated_line_kernel / get_pca_endpoints (:35-237).
+// [ext] OpenCV / numpy-LAPACK semantics restated exactly as in oracle/src/orc_morph.c, orc_masks.c,
+// orc_contours.c, orc_draw.c (those are the bit-level specification; parity unpinned vs cv2).
+//
+// The reference's dominant cost -- two full-frame dilations with a ~100x100 structuring element per
+// line fragment -- becomes one workgroup per fragment end point working on the (15 + K)^2 support in LDS.
+#include "cpe_dev.h"
+
+namespace cpe {
+
+int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
+int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *touch, int *roots, FrameState *st,
+                hipStream_t s);
+
+namespace {
+
+// ---- rectangular erode / dilate (anchor kw/2, kh/2; same offsets for both; border never wins) -------------
+__global__ __launch_bounds__(256) void k_morph_rect(const uint8_t *__restrict__ src, size_t total, int h, int w, int kw,
+                                                    int kh, int dilate, uint8_t *__restrict__ dst)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const size_t N = (size_t)h * w;
+    const size_t f = gi / N;
+    const int i = (int)(gi - f * N);
+    const int y = i / w, x = i - y * w;
+    const uint8_t *im = src + f * N;
+    const int ax = kw / 2, ay = kh / 2;
+    bool res = !dilate;
+    for (int ky = 0; ky < kh; ky++) {
+        int yy = y + ky - ay;
+        if (yy < 0 || yy >= h) continue;
+        for (int kx = 0; kx < kw; kx++) {
+            int xx = x + kx - ax;
+            if (xx < 0 || xx >= w) continue;
+            bool v = im[(size_t)yy * w + xx] != 0;
+            if (dilate) res = res || v;
+            else res = res && v;
+        }
+    }
+    dst[gi] = res ? 255 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_and2(const uint8_t *a, const uint8_t *b, size_t total, uint8_t *dst)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < total) dst[gi] = (a[gi] && b[gi]) ? 255 : 0;
+}
+__global__ __launch_bounds__(256) void k_and3(const uint8_t *a, const uint8_t *b, const uint8_t *c, size_t total, uint8_t *dst)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < total) dst[gi] = (a[gi] & b[gi]) & c[gi];
+}
+__global__ __launch_bounds__(256) void k_or_and(const uint8_t *a, const uint8_t *b, const uint8_t *c, size_t total, uint8_t *dst)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < total) dst[gi] = ((a[gi] ? 255 : 0) | (b[gi] ? 255 : 0)) & c[gi];
+}
+
+// ---- joints: polygon-moment centroids inside the region rectangle, in cv2.findContours order ----------
+__global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restrict__ jm, int h, int w,
+                                                        const int *__restrict__ roots, FrameState *__restrict__ st,
+                                                        int *__restrict__ jtmp /* n*MAXJ*3 */)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st[f].status != CPE_ST_OK) return;
+    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    const size_t N = (size_t)h * w;
+    const int root = roots[(size_t)f * MAXROOTS + k];
+    MaskPred nz{jm + f * N, w, h};
+    StatVisitor sv;
+    if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { st[f].overflow = 1; return; }
+    sv.finish();
+    double m00, m10, m01;
+    moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
+    if (m00 == 0) return;
+    int cx = (int)(m10 / m00), cy = (int)(m01 / m00);
+    atomicAdd(&st[f].n_joints_all, 1);
+    const int *r = st[f].rect;
+    if (!(r[0] <= cx && cx < r[0] + r[2] && r[1] <= cy && cy < r[1] + r[3])) return;
+    int q = atomicAdd(&st[f].n_joints, 1);
+    if (q >= MAXJ) { st[f].overflow = 1; return; }
+    int *o = jtmp + ((size_t)f * MAXJ + q) * 3;
+    o[0] = cx; o[1] = cy; o[2] = root;
+}
+
+__global__ __launch_bounds__(256) void k_joint_sort(FrameState *__restrict__ st, const int *__restrict__ jtmp,
+                                                    int *__restrict__ joints /* n*MAXJ*2 */)
+{
+    const int f = blockIdx.x;
+    const int nj = min(st[f].n_joints, MAXJ);
+    const int *src = jtmp + (size_t)f * MAXJ * 3;
+    int *dst = joints + (size_t)f * MAXJ * 2;
+    for (int i = threadIdx.x; i < nj; i += 256) {
+        int ki = src[3 * i + 2], rank = 0;
+        for (int j = 0; j < nj; j++) rank += (src[3 * j + 2] > ki) ? 1 : 0;  // latest discovery first
+        dst[2 * rank] = src[3 * i];
+        dst[2 * rank + 1] = src[3 * i + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st[f].n_joints = nj;
+}
+
+// ---- separable fixed-point Gaussian blur on u8 (cv2.GaussianBlur (7,7) and (19,19), sigma 0) ------------
+struct Taps { int k[19]; int r; int shift; };
+
+__global__ __launch_bounds__(256) void k_blur_h(const uint8_t *__restrict__ src, size_t total, int h, int w, Taps t,
+                                                uint16_t *__restrict__ tmp)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const size_t N = (size_t)h * w;
+    const size_t f = gi / N;
+    const int i = (int)(gi - f * N);
+    const int y = i / w, x = i - y * w;
+    const uint8_t *row = src + f * N + (size_t)y * w;
+    int s = 0;
+    for (int j = -t.r; j <= t.r; j++) s += t.k[j + t.r] * row[reflect101(x + j, w)];
+    tmp[gi] = (uint16_t)s;
+}
+__global__ __launch_bounds__(256) void k_blur_v(const uint16_t *__restrict__ tmp, size_t total, int h, int w, Taps t,
+                                                uint8_t *__restrict__ dst)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const size_t N = (size_t)h * w;
+    const size_t f = gi / N;
+    const int i = (int)(gi - f * N);
+    const int y = i / w, x = i - y * w;
+    const uint16_t *im = tmp + f * N;
+    int s = 0;
+    for (int j = -t.r; j <= t.r; j++) s += t.k[j + t.r] * (int)im[(size_t)reflect101(y + j, h) * w + x];
+    dst[gi] = (uint8_t)((s + (1 << (t.shift - 1))) >> t.shift);
+}
+
+// ---- saturated spot -> minEnclosingCircle -> ellipse erased from a 255 plane -----------------------
+__global__ __launch_bounds__(64) void k_spot_area(const uint8_t *__restrict__ g19, int h, int w,
+                                                  const int *__restrict__ roots, FrameState *__restrict__ st,
+                                                  unsigned long long *__restrict__ best)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st[f].status != CPE_ST_OK) return;
+    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    const size_t N = (size_t)h * w;
+    const int root = roots[(size_t)f * MAXROOTS + k];
+    ThreshPred nz{g19 + f * N, w, h, 240};
+    StatVisitor sv;
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
+    sv.finish();
+    long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;
+    // max(contours, key=contourArea): first maximum in list order = latest discovered among equals; area 0 counts
+    unsigned long long key = ((unsigned long long)(a2 + 1) << 24) | (unsigned long long)(root & 0xFFFFFF);
+    atomicMax(&best[f], key);
+}
+
+struct VertVisitor {
+    int *v;
+    int cap, n = 0;
+    __device__ __forceinline__ void point(int x, int y, bool vertex)
+    {
+        if (!vertex) return;
+        if (n < cap) { v[2 * n] = x; v[2 * n + 1] = y; }
+        n++;
+    }
+};
+
+__device__ __forceinline__ float normf2(float x, float y) { return (float)sqrt((double)x * x + (double)y * y); }
+constexpr float MEC_EPS = 1.0e-4f;
+
+__device__ void circle3(const float *px, const float *py, float &cx_, float &cy_, float &r_)
+{
+    float v1x = px[1] - px[0], v1y = py[1] - py[0];
+    float v2x = px[2] - px[0], v2y = py[2] - py[0];
+    float m1x = (px[0] + px[1]) / 2.0f, m1y = (py[0] + py[1]) / 2.0f;
+    float c1 = m1x * v1x + m1y * v1y;
+    float m2x = (px[0] + px[2]) / 2.0f, m2y = (py[0] + py[2]) / 2.0f;
+    float c2 = m2x * v2x + m2y * v2y;
+    float det = v1x * v2y - v1y * v2x;
+    if (fabsf(det) <= MEC_EPS) {
+        float d1 = (px[0] - px[1]) * (px[0] - px[1]) + (py[0] - py[1]) * (py[0] - py[1]);
+        float d2 = (px[0] - px[2]) * (px[0] - px[2]) + (py[0] - py[2]) * (py[0] - py[2]);
+        float d3 = (px[1] - px[2]) * (px[1] - px[2]) + (py[1] - py[2]) * (py[1] - py[2]);
+        float mx = d1 > d2 ? d1 : d2;
+        mx = mx > d3 ? mx : d3;
+        r_ = sqrtf(mx) * 0.5f + MEC_EPS;
+        if (d1 >= d2 && d1 >= d3) { cx_ = (px[0] + px[1]) * 0.5f; cy_ = (py[0] + py[1]) * 0.5f; }
+        else if (d2 >= d1 && d2 >= d3) { cx_ = (px[0] + px[2]) * 0.5f; cy_ = (py[0] + py[2]) * 0.5f; }
+        else { cx_ = (px[1] + px[2]) * 0.5f; cy_ = (py[1] + py[2]) * 0.5f; }
+        return;
+    }
+    float cx = (c1 * v2y - c2 * v1y) / det;
+    float cy = (v1x * c2 - v2x * c1) / det;
+    cx_ = cx; cy_ = cy;
+    cx -= px[0]; cy -= py[0];
+    r_ = (float)sqrt((double)(cx * cx + cy * cy)) + MEC_EPS;
+}
+
+__device__ void mec_third(const int *p, int i, int j, float &cx, float &cy, float &r)
+{
+    cx = (float)(p[2 * j] + p[2 * i]) / 2.0f;
+    cy = (float)(p[2 * j + 1] + p[2 * i + 1]) / 2.0f;
+    r = normf2((float)(p[2 * j] - p[2 * i]), (float)(p[2 * j + 1] - p[2 * i + 1])) / 2.0f + MEC_EPS;
+    for (int k = 0; k < j; k++) {
+        float dx = cx - (float)p[2 * k], dy = cy - (float)p[2 * k + 1];
+        if (normf2(dx, dy) < r) continue;
+        float fx[3] = {(float)p[2 * i], (float)p[2 * j], (float)p[2 * k]};
+        float fy[3] = {(float)p[2 * i + 1], (float)p[2 * j + 1], (float)p[2 * k + 1]};
+        float ncx, ncy, nr = 0;
+        circle3(fx, fy, ncx, ncy, nr);
+        if (nr > 0) { r = nr; cx = ncx; cy = ncy; }
+    }
+}
+__device__ void mec_second(const int *p, int i, float &cx, float &cy, float &r)
+{
+    cx = (float)(p[0] + p[2 * i]) / 2.0f;
+    cy = (float)(p[1] + p[2 * i + 1]) / 2.0f;
+    r = normf2((float)(p[0] - p[2 * i]), (float)(p[1] - p[2 * i + 1])) / 2.0f + MEC_EPS;
+    for (int j = 1; j < i; j++) {
+        float dx = cx - (float)p[2 * j], dy = cy - (float)p[2 * j + 1];
+        if (normf2(dx, dy) < r) continue;
+        float ncx, ncy, nr = 0;
+        mec_third(p, i, j, ncx, ncy, nr);
+        if (nr > 0) { r = nr; cx = ncx; cy = ncy; }
+    }
+}
+__device__ void min_enclosing_circle(const int *p, int n, float &cx, float &cy, float &r)
+{
+    cx = cy = r = 0;
+    if (n == 0) return;
+    if (n == 1) { cx = (float)p[0]; cy = (float)p[1]; r = MEC_EPS; return; }
+    if (n == 2) {
+        cx = ((float)p[0] + (float)p[2]) / 2.0f;
+        cy = ((float)p[1] + (float)p[3]) / 2.0f;
+        double dx = p[0] - p[2], dy = p[1] - p[3];
+        r = (float)(sqrt(dx * dx + dy * dy) / 2.0) + MEC_EPS;
+        return;
+    }
+    cx = (float)(p[0] + p[2]) / 2.0f;
+    cy = (float)(p[1] + p[3]) / 2.0f;
+    r = normf2((float)(p[0] - p[2]), (float)(p[1] - p[3])) / 2.0f + MEC_EPS;
+    for (int i = 2; i < n; i++) {
+        float dx = (float)p[2 * i] - cx, dy = (float)p[2 * i + 1] - cy;
+        float d = normf2(dx, dy);
+        if (d < r) continue;
+        float ncx, ncy, nr = 0;
+        mec_second(p, i, ncx, ncy, nr);
+        if (nr > 0) { r = nr; cx = ncx; cy = ncy; }
+    }
+}
+
+constexpr int XY_SHIFT = 16;
+constexpr int XY_ONE = 1 << XY_SHIFT;
+
+__device__ __forceinline__ void putz(uint8_t *img, int h, int w, int x, int y)
+{
+    if (x >= 0 && x < w && y >= 0 && y < h) img[(size_t)y * w + x] = 0;
+}
+
+__device__ void line2z(uint8_t *img, int h, int w, long long p1x, long long p1y, long long p2x, long long p2y)
+{
+    long long dx = p2x - p1x, dy = p2y - p1y;
+    long long j = dx < 0 ? -1 : 0, ax = (dx ^ j) - j;
+    long long i = dy < 0 ? -1 : 0, ay = (dy ^ i) - i;
+    long long x_step, y_step;
+    int ecount;
+    if (ax > ay) {
+        dy = (dy ^ j) - j;
+        p1x ^= p2x & j; p2x ^= p1x & j; p1x ^= p2x & j;
+        p1y ^= p2y & j; p2y ^= p1y & j; p1y ^= p2y & j;
+        x_step = XY_ONE;
+        y_step = dy * (1 << XY_SHIFT) / (ax | 1);
+        ecount = (int)((p2x - p1x) >> XY_SHIFT);
+    } else {
+        dx = (dx ^ i) - i;
+        p1x ^= p2x & i; p2x ^= p1x & i; p1x ^= p2x & i;
+        p1y ^= p2y & i; p2y ^= p1y & i; p1y ^= p2y & i;
+        x_step = dx * (1 << XY_SHIFT) / (ay | 1);
+        y_step = XY_ONE;
+        ecount = (int)((p2y - p1y) >> XY_SHIFT);
+    }
+    (void)x_step; (void)y_step;
+    p1x += (XY_ONE >> 1);
+    p1y += (XY_ONE >> 1);
+    putz(img, h, w, (int)((p2x + (XY_ONE >> 1)) >> XY_SHIFT), (int)((p2y + (XY_ONE >> 1)) >> XY_SHIFT));
+    if (ax > ay) {
+        p1x >>= XY_SHIFT;
+        while (ecount >= 0) {
+            putz(img, h, w, (int)p1x, (int)(p1y >> XY_SHIFT));
+            p1x++;
+            p1y += y_step;
+            ecount--;
+        }
+    } else {
+        p1y >>= XY_SHIFT;
+        while (ecount >= 0) {
+            putz(img, h, w, (int)(p1x >> XY_SHIFT), (int)p1y);
+            p1x += x_step;
+            p1y++;
+            ecount--;
+        }
+    }
+}
+
+// FillConvexPoly(shift = 16, colour 0)
+__device__ void fill_convex_poly_z(uint8_t *img, int h, int w, const long long *vx, const long long *vy, int npts)
+{
+    const int shift = XY_SHIFT;
+    struct { int idx, di; long long x, dx; int ye; } edge[2];
+    int delta = 1 << shift >> 1;
+    int i, y, imin = 0, edges = npts;
+    long long xmin, xmax, ymin, ymax;
+    const int delta1 = XY_ONE >> 1, delta2 = XY_ONE >> 1;
+    long long p0x = vx[npts - 1], p0y = vy[npts - 1];
+    xmin = xmax = vx[0];
+    ymin = ymax = vy[0];
+    for (i = 0; i < npts; i++) {
+        long long px = vx[i], py = vy[i];
+        if (py < ymin) { ymin = py; imin = i; }
+        if (py > ymax) ymax = py;
+        if (px > xmax) xmax = px;
+        if (px < xmin) xmin = px;
+        line2z(img, h, w, p0x, p0y, px, py);
+        p0x = px; p0y = py;
+    }
+    xmin = (xmin + delta) >> shift;
+    xmax = (xmax + delta) >> shift;
+    ymin = (ymin + delta) >> shift;
+    ymax = (ymax + delta) >> shift;
+    if (npts < 3 || (int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w || (int)ymin >= h) return;
+    if (ymax > h - 1) ymax = h - 1;
+    edge[0].idx = edge[1].idx = imin;
+    edge[0].ye = edge[1].ye = y = (int)ymin;
+    edge[0].di = 1;
+    edge[1].di = npts - 1;
+    edge[0].x = edge[1].x = -XY_ONE;
+    edge[0].dx = edge[1].dx = 0;
+    do {
+        for (i = 0; i < 2; i++) {
+            if (y >= edge[i].ye) {
+                int idx0 = edge[i].idx, di = edge[i].di;
+                int idx = idx0 + di;
+                if (idx >= npts) idx -= npts;
+                int ty = 0;
+                for (; edges-- > 0;) {
+                    ty = (int)((vy[idx] + delta) >> shift);
+                    if (ty > y) {
+                        long long xs = vx[idx0], xe = vx[idx];
+                        edge[i].ye = ty;
+                        edge[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        edge[i].x = xs;
+                        edge[i].idx = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di;
+                    if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int left = 0, right = 1;
+            if (edge[0].x > edge[1].x) { left = 1; right = 0; }
+            int xx1 = (int)((edge[left].x + delta1) >> XY_SHIFT);
+            int xx2 = (int)((edge[right].x + delta2) >> XY_SHIFT);
+            if (xx2 >= 0 && xx1 < w) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= w) xx2 = w - 1;
+                for (int x = xx1; x <= xx2; x++) img[(size_t)y * w + x] = 0;
+            }
+        }
+        edge[0].x += edge[0].dx;
+        edge[1].x += edge[1].dx;
+    } while (++y <= (int)ymax);
+}
+
+__device__ void ellipse_fill_z(uint8_t *img, int h, int w, int cx, int cy, int a, int b)
+{
+    long long ccx = (long long)cx << XY_SHIFT, ccy = (long long)cy << XY_SHIFT;
+    long long aw = llabs((long long)a << XY_SHIFT), ah = llabs((long long)b << XY_SHIFT);
+    int delta = (int)(((aw > ah ? aw : ah) + (XY_ONE >> 1)) >> XY_SHIFT);
+    delta = delta < 3 ? 90 : delta < 10 ? 30 : delta < 15 ? 18 : 5;
+    long long vx[400], vy[400];
+    int nv = 0;
+    long long prevx = -1, prevy = -1;
+    bool have_prev = false;
+    for (int i = 0; i < 360 + delta; i += delta) {
+        int ang = i > 360 ? 360 : i;
+        double sx = (double)(float)sin((450 - ang) * 0.017453292519943295769236907684886);
+        double sy = (double)(float)sin(ang * 0.017453292519943295769236907684886);
+        if ((450 - ang) % 90 == 0) { int q = ((450 - ang) / 90) % 4; sx = q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 0 : -1; }
+        if (ang % 90 == 0) { int q = (ang / 90) % 4; sy = q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 0 : -1; }
+        double x = (double)aw * sx, y = (double)ah * sy;
+        double ptx = (double)ccx + x, pty = (double)ccy + y;
+        long long qx = (long long)(int)rint(ptx / XY_ONE) << XY_SHIFT, qy = (long long)(int)rint(pty / XY_ONE) << XY_SHIFT;
+        qx += (int)rint(ptx - (double)qx);
+        qy += (int)rint(pty - (double)qy);
+        if (!have_prev || qx != prevx || qy != prevy) {
+            vx[nv] = qx; vy[nv] = qy; nv++;
+            prevx = qx; prevy = qy; have_prev = true;
+        }
+    }
+    if (nv == 1) { vx[0] = vx[1] = ccx; vy[0] = vy[1] = ccy; nv = 2; }
+    fill_convex_poly_z(img, h, w, vx, vy, nv);
+}
+
+// one thread per frame: contour of the largest saturated blob -> circle -> ellipse erased from cm (pre-set to 255)
+__global__ __launch_bounds__(64) void k_spot_ellipse(const uint8_t *__restrict__ g19, int n, int h, int w,
+                                                     const unsigned long long *__restrict__ best, FrameState *__restrict__ st,
+                                                     int *__restrict__ verts /* n*MAXV*2 */, uint8_t *__restrict__ cm)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    FrameState &S = st[f];
+    if (S.status != CPE_ST_OK) return;
+    if (best[f] == 0) { S.status = CPE_ST_NO_SPOT; return; }
+    const size_t N = (size_t)h * w;
+    const int root = (int)(best[f] & 0xFFFFFF);
+    ThreshPred nz{g19 + f * N, w, h, 240};
+    VertVisitor vv{verts + (size_t)f * MAXV * 2, MAXV};
+    trace_border(nz, root % w, root / w, false, vv, 8 * (w + h) + (1 << 20));
+    if (vv.n > MAXV) { S.overflow = 1; vv.n = MAXV; }
+    float cx, cy, rad;
+    min_enclosing_circle(vv.v, vv.n, cx, cy, rad);
+    int icx = (int)cx, icy = (int)cy;
+    int cr0 = (int)rad;
+    int cr = rad < 30 ? cr0 + 20 : cr0 + 5;
+    int minor = cr + 20 > 1 ? cr + 20 : 1;
+    int a = (int)rint((cr + 40) / 2.0), b = (int)rint(minor / 2.0);
+    ellipse_fill_z(cm + f * N, h, w, icx, icy, a, b);
+    S.r0 = cr0;
+    S.spot[0] = icx; S.spot[1] = icy; S.spot[2] = a; S.spot[3] = b;
+}
+
+// ---- line-fragment expansion ------------------------------------------------------------------------
+
+__device__ __forceinline__ double sign1(double a, double b) { return b >= 0 ? fabs(a) : -fabs(a); }
+
+// numpy.linalg.eig of a symmetric 2x2 as LAPACK dgeev (dlanv2) orders and signs it
+__device__ void eig2_lapack(double a, double b, double c, double d, double *w, double *V)
+{
+    double cs, sn;
+    if (c == 0) {
+        cs = 1; sn = 0;
+    } else if (b == 0) {
+        cs = 0; sn = 1;
+        double t = d; d = a; a = t; b = -c; c = 0;
+    } else if ((a - d) == 0 && sign1(1, b) != sign1(1, c)) {
+        cs = 1; sn = 0;
+    } else {
+        double temp = a - d, p = 0.5 * temp;
+        double bcmax = fmax(fabs(b), fabs(c));
+        double bcmis = fmin(fabs(b), fabs(c)) * sign1(1, b) * sign1(1, c);
+        double scale = fmax(fabs(p), bcmax);
+        double z = (p / scale) * p + (bcmax / scale) * bcmis;
+        if (z >= 4.0 * 2.220446049250313e-16) {
+            z = p + sign1(sqrt(scale) * sqrt(z), p);
+            a = d + z;
+            d = d - (bcmax / z) * bcmis;
+            double tau = hypot(c, z);
+            cs = z / tau;
+            sn = c / tau;
+            b = b - c;
+            c = 0;
+        } else {
+            double sigma = b + c;
+            double tau = hypot(sigma, temp);
+            cs = sqrt(0.5 * (1 + fabs(sigma) / tau));
+            sn = -(p / (tau * cs)) * sign1(1, sigma);
+            double aa = a * cs + b * sn, bb = -a * sn + b * cs, cc = c * cs + d * sn, dd = -c * sn + d * cs;
+            a = aa * cs + cc * sn; b = bb * cs + dd * sn; c = -aa * sn + cc * cs; d = -bb * sn + dd * cs;
+            temp = 0.5 * (a + d);
+            a = temp; d = temp;
+        }
+    }
+    w[0] = a; w[1] = d;
+    double v1x = cs, v1y = sn;
+    double x0 = (a != d) ? -b / (a - d) : 0.0, x1 = 1.0;
+    double v2x = cs * x0 - sn * x1, v2y = sn * x0 + cs * x1;
+    double n2 = sqrt(v2x * v2x + v2y * v2y);
+    v2x /= n2; v2y /= n2;
+    V[0] = v1x; V[1] = v2x; V[2] = v1y; V[3] = v2y;
+}
+
+struct SegVisitor {
+    float *pts;  // 200 x 2
+    int n = 0;
+    __device__ __forceinline__ void point(int x, int y, bool vertex)
+    {
+        if (!vertex) return;
+        if (n < 200) { pts[2 * n] = (float)x; pts[2 * n + 1] = (float)y; }
+        n++;
+    }
+};
+
+// one thread per fragment: CHAIN_APPROX_SIMPLE vertices (5..200) -> PCA end points, angle, length
+__global__ __launch_bounds__(64) void k_seg_trace(const uint8_t *__restrict__ base, int h, int w, int which,
+                                                  const int *__restrict__ roots, FrameState *__restrict__ st,
+                                                  SegRec *__restrict__ segs /* n*MAXSEG */)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st[f].status != CPE_ST_OK) return;
+    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    const size_t N = (size_t)h * w;
+    const int root = roots[(size_t)f * MAXROOTS + k];
+    MaskPred nz{base + f * N, w, h};
+    float pts[400];
+    SegVisitor sv{pts};
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
+    const int n = sv.n;
+    if (n < 5 || n > 200) return;
+    // get_pca_endpoints
+    float mx = 0, my = 0;
+    for (int i = 0; i < n; i++) { mx += pts[2 * i]; my += pts[2 * i + 1]; }
+    mx = mx / (float)n; my = my / (float)n;
+    double ax = 0, ay = 0;
+    for (int i = 0; i < n; i++) { ax += (double)(pts[2 * i] - mx); ay += (double)(pts[2 * i + 1] - my); }
+    ax /= n; ay /= n;
+    double sxx = 0, sxy = 0, syy = 0;
+    for (int i = 0; i < n; i++) {
+        double dx = (double)(pts[2 * i] - mx) - ax, dy = (double)(pts[2 * i + 1] - my) - ay;
+        sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+    }
+    double fct = 1.0 / (n - 1);
+    sxx *= fct; sxy *= fct; syy *= fct;
+    double wv[2], V[4];
+    eig2_lapack(sxx, sxy, sxy, syy, wv, V);
+    int kk = wv[1] > wv[0] ? 1 : 0;
+    double ux = V[0 + kk], uy = V[2 + kk];
+    int imin = 0, imax = 0;
+    double pmin = 0, pmax = 0;
+    for (int i = 0; i < n; i++) {
+        double pr = (double)(pts[2 * i] - mx) * ux + (double)(pts[2 * i + 1] - my) * uy;
+        if (i == 0 || pr < pmin) { pmin = pr; imin = i; }
+        if (i == 0 || pr > pmax) { pmax = pr; imax = i; }
+    }
+    float p1x = pts[2 * imin], p1y = pts[2 * imin + 1], p2x = pts[2 * imax], p2y = pts[2 * imax + 1];
+    float dx = p2x - p1x, dy = p2y - p1y;
+    float length = (float)hypot((double)dx, (double)dy);
+    if (length < 1e-8) return;
+    float at = (float)atan2((double)dy, (double)dx);
+    float deg = at * (float)(180.0 / 3.14159265358979323846);
+    int q = atomicAdd(&st[f].n_seg[which], 1);
+    if (q >= MAXSEG) { st[f].overflow = 1; return; }
+    SegRec &r = segs[(size_t)f * MAXSEG + q];
+    r.p1x = p1x; r.p1y = p1y; r.p2x = p2x; r.p2y = p2y; r.angle = -deg; r.len = length; r.valid = 1;
+}
+
+// median angle (np.median of float32) and maximum length per frame
+__global__ __launch_bounds__(256) void k_seg_global(FrameState *__restrict__ st, int which, const SegRec *__restrict__ segs)
+{
+    const int f = blockIdx.x, t = threadIdx.x;
+    __shared__ float s_lo, s_hi;
+    __shared__ unsigned int s_len;
+    const int nv = min(st[f].n_seg[which], MAXSEG);
+    const SegRec *S = segs + (size_t)f * MAXSEG;
+    if (t == 0) { s_lo = 0; s_hi = 0; s_len = 0; }
+    __syncthreads();
+    const int k_hi = nv / 2, k_lo = (nv & 1) ? nv / 2 : nv / 2 - 1;
+    for (int i = t; i < nv; i += 256) {
+        float ai = S[i].angle;
+        int rank = 0;
+        for (int j = 0; j < nv; j++) {
+            float aj = S[j].angle;
+            rank += (aj < ai || (aj == ai && j < i)) ? 1 : 0;
+        }
+        if (rank == k_lo) s_lo = ai;
+        if (rank == k_hi) s_hi = ai;
+        atomicMax(&s_len, __float_as_uint(S[i].len));  // lengths are positive: uint order == float order
+    }
+    __syncthreads();
+    if (t == 0) {
+        st[f].gang[which] = (nv & 1) ? s_hi : (float)(((double)s_lo + (double)s_hi) / 2.0);
+        st[f].glen[which] = __uint_as_float(s_len);
+    }
+}
+
+// one workgroup per fragment end point: 15x15 patch of the mask dilated by the rotated line kernel
+// (reflected, as cv2.dilate does), eroded 3x3, OR-ed into exp.  Works on the (15 + ks)^2 support in LDS.
+constexpr int EXP_MAXKS = 176;
+constexpr int EXP_REG = 15 + EXP_MAXKS + 2;
+__global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ base, int h, int w, int which,
+                                                    FrameState *__restrict__ st, const SegRec *__restrict__ segs,
+                                                    uint8_t *__restrict__ exp)
+{
+    __shared__ uint8_t dil[EXP_REG * EXP_REG];
+    __shared__ short koff[4096][2];
+    __shared__ short ppix[225][2];
+    __shared__ int s_nk, s_np;
+    const int f = blockIdx.y, t = threadIdx.x;
+    FrameState &S = st[f];
+    if (S.status != CPE_ST_OK) return;
+    const int seg = blockIdx.x >> 1, e = blockIdx.x & 1;
+    if (seg >= min(S.n_seg[which], MAXSEG)) return;
+    const SegRec r = segs[(size_t)f * MAXSEG + seg];
+    const float glen = S.glen[which], gang = S.gang[which];
+    if ((double)r.len > 0.8 * (double)glen) return;
+    const int ks = 91 + S.r0;
+    if (ks > EXP_MAXKS) { if (t == 0) S.overflow = 1; return; }
+    const float ak = fabsf(r.angle - gang) > 5.0f ? gang : r.angle;
+    const int a = ks / 2, half = 7;
+    const size_t N = (size_t)h * w;
+    const uint8_t *bm = base + f * N;
+    const int cx = (int)rint((double)(e ? r.p2x : r.p1x)), cy = (int)rint((double)(e ? r.p2y : r.p1y));
+    const int x1 = max(cx - half, 0), x2 = min(cx + half + 1, w), y1 = max(cy - half, 0), y2 = min(cy + half + 1, h);
+    if (t == 0) { s_nk = 0; s_np = 0; }
+    __syncthreads();
+    // rotated line kernel: getRotationMatrix2D + warpAffine(INTER_NEAREST) of the centre row
+    {
+        const int c = ks / 2;
+        double ar = (double)ak * 3.1415926535897932384626433832795 / 180.0;
+        double alpha = cos(ar), beta = sin(ar);
+        double M[6] = {alpha, beta, (1 - alpha) * c - beta * c, -beta, alpha, beta * c + (1 - alpha) * c};
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        double A11 = M[4] * D, A22 = M[0] * D;
+        double iM[6];
+        iM[0] = A11; iM[1] = M[1] * (-D); iM[3] = M[3] * (-D); iM[4] = A22;
+        double b1 = -iM[0] * M[2] - iM[1] * M[5];
+        double b2 = -iM[3] * M[2] - iM[4] * M[5];
+        iM[2] = b1; iM[5] = b2;
+        for (int i = t; i < ks * ks; i += 256) {
+            int y = i / ks, x = i - y * ks;
+            int X0 = (int)rint((iM[1] * y + iM[2]) * 1024) + 512;
+            int Y0 = (int)rint((iM[4] * y + iM[5]) * 1024) + 512;
+            int adelta = (int)rint(iM[0] * x * 1024), bdelta = (int)rint(iM[3] * x * 1024);
+            int X = (X0 + adelta) >> 10, Y = (Y0 + bdelta) >> 10;
+            if (X >= 0 && X < ks && Y == c) {
+                int q = atomicAdd(&s_nk, 1);
+                if (q < 4096) { koff[q][0] = (short)(x - a); koff[q][1] = (short)(y - a); }
+            }
+        }
+    }
+    for (int i = t; i < 225; i += 256) {
+        int py = y1 + i / 15, px = x1 + i % 15;
+        if (py < y2 && px < x2 && bm[(size_t)py * w + px]) {
+            int q = atomicAdd(&s_np, 1);
+            ppix[q][0] = (short)px; ppix[q][1] = (short)py;
+        }
+    }
+    // support box (global coords) with a 1-px margin for the erosion
+    const int bx1 = x1 - a - 1, by1 = y1 - a - 1;
+    const int bw = (x2 - x1) + 2 * a + 2, bh = (y2 - y1) + 2 * a + 2;
+    for (int i = t; i < bw * bh; i += 256) dil[i] = 0;
+    __syncthreads();
+    const int nk = min(s_nk, 4096), np = s_np;
+    if (s_nk > 4096 && t == 0) S.overflow = 1;
+    for (int i = t; i < nk * np; i += 256) {
+        int p = i / nk, k = i - p * nk;
+        int xx = ppix[p][0] - koff[k][0], yy = ppix[p][1] - koff[k][1];
+        if (xx >= 0 && xx < w && yy >= 0 && yy < h) dil[(yy - by1) * bw + (xx - bx1)] = 1;
+    }
+    __syncthreads();
+    uint8_t *ex = exp + f * N;
+    for (int i = t; i < bw * bh; i += 256) {
+        int ly = i / bw, lx = i - ly * bw;
+        int gy = by1 + ly, gx = bx1 + lx;
+        if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+        bool all = true;
+        for (int dy = -1; dy <= 1 && all; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                int yy = gy + dy, xx = gx + dx;
+                if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                int ly2 = ly + dy, lx2 = lx + dx;
+                bool v = (ly2 >= 0 && ly2 < bh && lx2 >= 0 && lx2 < bw) ? dil[ly2 * bw + lx2] != 0 : false;
+                if (!v) { all = false; break; }
+            }
+        if (all) ex[(size_t)gy * w + gx] = 255;
+    }
+}
+
+__global__ void k_masks_reset(FrameState *st, int n, unsigned long long *best)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    st[f].n_joints = 0; st[f].n_joints_all = 0; st[f].n_seg[0] = 0; st[f].n_seg[1] = 0;
+    st[f].gang[0] = st[f].gang[1] = 0; st[f].glen[0] = st[f].glen[1] = 0;
+    best[f] = 0;
+}
+
+inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+
+// cv2.GaussianBlur(img,(7,7),0) for indexing_data (util_cylinder.py:1433)
+int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *dst, hipStream_t s)
+{
+    const size_t total = (size_t)h * w * n;
+    Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, src, total, h, w, t7, tmp16);
+    hipLaunchKernelGGL(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, tmp16, total, h, w, t7, dst);
+    CPE_CHECK_LAUNCH("blur7_u8");
+    return CPE_OK;
+}
+
+// a-2: hmask, vmask, joints mask (no dependence on the region stage)
+int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s)
+{
+    const size_t total = (size_t)h * w * n;
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 20, 1, 0, B.tmpA);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 20, 1, 1, B.hmask);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 1, 20, 0, B.tmpA);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 1, 20, 1, B.vmask);
+    hipLaunchKernelGGL(k_and2, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.vmask, total, B.joints_mask);
+    CPE_CHECK_LAUNCH("joints_mask_stage");
+    return CPE_OK;
+}
+
+// a-2/a-4 (joint centroids inside rect), a-5 (spot / roi masks), a-6 (expansion).  Needs st[].rect and mc.
+int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
+{
+    const size_t total = (size_t)h * w * n;
+    int rc;
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
+    // joints
+    if ((rc = ccl_label(B.joints_mask, n, h, w, 0, 0, 1, B.lab, s)) != CPE_OK) return rc;
+    if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
+    hipLaunchKernelGGL(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots, st, B.jtmp);
+    hipLaunchKernelGGL(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
+    // spot
+    Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
+    hipLaunchKernelGGL(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, gray, total, h, w, t19, B.tmp16);
+    hipLaunchKernelGGL(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, B.tmp16, total, h, w, t19, B.g19);
+    if ((rc = ccl_label(B.g19, n, h, w, 240, 0, 1, B.lab, s)) != CPE_OK) return rc;
+    if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
+    hipLaunchKernelGGL(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots, st, B.best);
+    (void)hipMemsetAsync(B.cm, 255, total, s);
+    hipLaunchKernelGGL(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best, st, B.verts, B.cm);
+    // roi masks: (mask & circle_mask & mask_contour) opened 3x3
+    hipLaunchKernelGGL(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.cm, B.mc, total, B.tmpA);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_h);
+    hipLaunchKernelGGL(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.vmask, B.cm, B.mc, total, B.tmpA);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
+    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_v);
+    CPE_CHECK_LAUNCH("masks_stage spot");
+    // expansion
+    for (int which = 0; which < 2; which++) {
+        const uint8_t *roi = which ? B.roi_v : B.roi_h;
+        uint8_t *base = which ? B.base_v : B.base_h;
+        uint8_t *exp = which ? B.exp_v : B.exp_h;
+        hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, roi, total, h, w, 3, 3, 1, B.tmpA);
+        hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, base);
+        if ((rc = ccl_label(base, n, h, w, 0, 0, 1, B.lab, s)) != CPE_OK) return rc;
+        if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
+        hipLaunchKernelGGL(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, base, h, w, which, B.roots, st,
+                           B.segs + (size_t)which * n * MAXSEG);
+        hipLaunchKernelGGL(k_seg_global, dim3(n), dim3(256), 0, s, st, which, B.segs + (size_t)which * n * MAXSEG);
+        (void)hipMemsetAsync(B.tmpB, 0, total, s);
+        hipLaunchKernelGGL(k_seg_expand, dim3(MAXSEG * 2, n), dim3(256), 0, s, base, h, w, which, st,
+                           B.segs + (size_t)which * n * MAXSEG, B.tmpB);
+        hipLaunchKernelGGL(k_or_and, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, base, B.mc, total, exp);
+        CPE_CHECK_LAUNCH("masks_stage expand");
+    }
+    return CPE_OK;
+}
+
+}  // namespace cpe

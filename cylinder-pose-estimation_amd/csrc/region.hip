@@ -1,0 +1,524 @@
+// Stage a-3 on the GPU: detect_largest_blob (util_cylinder.py:1830-1899)
+//   L = LAB-L LUT(gray) -> CLAHE(4.5, 4x4) -> SimpleBlobDetector -> filled discs -> largest external
+//   contour -> convex hull -> filled hull mask (mask_contour) + boundingRect(max_contour).
+// [ext] OpenCV 4.5.5 semantics restated exactly as in oracle/src/orc_blob.c (parity unpinned vs cv2).
+//
+// SimpleBlobDetector = 17 binarisations (50..210 step 10).  Per threshold: foreground (8-conn) and
+// background (4-conn) labelling, one thread per component follows its Suzuki border (outer border of a
+// bright component / hole border of an enclosed dark one), Green-theorem moments, area + colour
+// filters, median border distance (one wavefront per blob), then the order-dependent cross-threshold
+// grouping runs as one wavefront per frame.  Suzuki-Abe starts every hole border at the pixel west of
+// the hole's raster-first pixel and every outer border at the component's raster-first pixel, so the
+// parallel formulation visits exactly the borders the sequential raster scan does.
+#include "cpe_dev.h"
+
+namespace cpe {
+
+int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
+int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *touch, int *roots, FrameState *st,
+                hipStream_t s);
+
+namespace {
+
+__constant__ uint8_t c_lab_l[256] = { 0, 1, 1, 2, 2, 3, 5, 5, 6, 7, 7, 8, 9, 9, 10, 11, 12, 12, 14, 15, 16, 17, 18, 19, 21, 23, 24, 25, 27, 27, 28, 30, 31, 33, 34, 35, 36, 38, 39, 40, 41, 42, 43, 45, 46, 47, 48, 50, 51, 52, 53, 54, 55, 57, 58, 59, 60, 61, 62, 63, 65, 66, 67, 68, 69, 70, 71, 73, 74, 75, 76, 77, 78, 79, 80, 82, 82, 83, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 119, 119, 121, 122, 123, 124, 125, 126, 127, 128, 129, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141, 142, 143, 144, 145, 146, 147, 148, 149, 150, 151, 152, 153, 154, 155, 156, 156, 157, 158, 159, 160, 161, 162, 163, 164, 165, 166, 167, 168, 169, 170, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 180, 181, 182, 183, 184, 185, 186, 187, 188, 189, 190, 191, 192, 193, 194, 195, 196, 196, 197, 198, 199, 200, 201, 202, 203, 204, 205, 206, 207, 208, 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 219, 220, 221, 222, 223, 224, 225, 226, 227, 228, 228, 229, 230, 231, 232, 233, 234, 235, 236, 237, 237, 238, 239, 240, 241, 242, 243, 244, 245, 245, 246, 247, 248, 249, 250, 251, 252, 253, 253, 254, 255 };
+
+__device__ __forceinline__ int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// ---- CLAHE ----------------------------------------------------------------------------------------
+struct ClaheGeom { int tilesX, tilesY, tw, th, eh, ew, clipLimit; float lutScale; };
+
+__global__ __launch_bounds__(256) void k_clahe_hist(const uint8_t *__restrict__ gray, int n, int h, int w, ClaheGeom g,
+                                                    int strips, unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int sh[256];
+    int b = blockIdx.x;
+    int strip = b % strips; b /= strips;
+    int tile = b % (g.tilesX * g.tilesY);
+    int f = b / (g.tilesX * g.tilesY);
+    int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t *im = gray + (size_t)f * h * w;
+    int rows_per = (g.th + strips - 1) / strips;
+    int y0 = strip * rows_per, y1 = min(g.th, y0 + rows_per);
+    for (int yy = y0; yy < y1; yy++) {
+        int gy = reflect101(ty * g.th + yy, h);
+        for (int xx = threadIdx.x; xx < g.tw; xx += 256) {
+            int gx = reflect101(tx * g.tw + xx, w);
+            atomicAdd(&sh[c_lab_l[im[(size_t)gy * w + gx]]], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned int v = sh[threadIdx.x];
+    if (v) atomicAdd(&hist[((size_t)f * g.tilesX * g.tilesY + tile) * 256 + threadIdx.x], v);
+}
+
+__global__ __launch_bounds__(256) void k_clahe_lut(unsigned int *__restrict__ hist, ClaheGeom g, uint8_t *__restrict__ lut)
+{
+    __shared__ int sh[256];
+    __shared__ int s_clipped;
+    unsigned int *hh = hist + (size_t)blockIdx.x * 256;
+    int t = threadIdx.x;
+    int v = (int)hh[t];
+    if (t == 0) s_clipped = 0;
+    __syncthreads();
+    if (g.clipLimit > 0 && v > g.clipLimit) {
+        atomicAdd(&s_clipped, v - g.clipLimit);
+        v = g.clipLimit;
+    }
+    __syncthreads();
+    int clipped = s_clipped;
+    int batch = clipped / 256, residual = clipped - batch * 256;
+    v += batch;
+    if (residual != 0) {
+        int stepr = max(256 / residual, 1);
+        // hist[i]++ for i = 0, stepr, 2*stepr, ... while i < 256 and fewer than residual increments
+        if (t % stepr == 0 && t / stepr < residual) v++;
+    }
+    sh[t] = v;
+    __syncthreads();
+    if (t == 0) {
+        int sum = 0;
+        for (int i = 0; i < 256; i++) { sum += sh[i]; sh[i] = sum; }
+    }
+    __syncthreads();
+    lut[(size_t)blockIdx.x * 256 + t] = (uint8_t)sat_u8((int)rintf((float)sh[t] * g.lutScale));
+}
+
+__global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ gray, size_t total, int h, int w,
+                                                     ClaheGeom g, const uint8_t *__restrict__ lut,
+                                                     uint8_t *__restrict__ dst)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    size_t N = (size_t)h * w;
+    size_t f = gi / N;
+    int i = (int)(gi - f * N);
+    int y = i / w, x = i - y * w;
+    float inv_tw = 1.0f / g.tw, inv_th = 1.0f / g.th;
+    float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0);
+    ty2 = min(ty2, g.tilesY - 1);
+    float txf = x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    float xa = txf - tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, g.tilesX - 1);
+    int v = c_lab_l[gray[gi]];
+    const uint8_t *lf = lut + f * g.tilesX * g.tilesY * 256;
+    const uint8_t *p1 = lf + (size_t)(ty1 * g.tilesX) * 256, *p2 = lf + (size_t)(ty2 * g.tilesX) * 256;
+    float a = (float)p1[tx1 * 256 + v] * xa1, b = (float)p1[tx2 * 256 + v] * xa;
+    float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
+    float res = (a + b) * ya1 + (c + d) * ya;
+    dst[gi] = (uint8_t)sat_u8((int)rintf(res));
+}
+
+// ---- blobs per threshold ----------------------------------------------------------------------------
+struct DistVisitor {
+    double cx, cy;
+    double *out;
+    int k = 0;
+    __device__ __forceinline__ void point(int x, int y, bool)
+    {
+        double dx = cx - (double)x, dy = cy - (double)y;
+        out[k++] = sqrt(dx * dx + dy * dy);
+    }
+};
+
+// one thread per component: outer border (is_hole = 0) or hole border (is_hole = 1)
+__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int thr, int is_hole,
+                                                   const int *__restrict__ roots, FrameState *__restrict__ st,
+                                                   BlobRec *__restrict__ blobs, int *__restrict__ blob_d,
+                                                   double *__restrict__ dists)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nr = min(st[f].n_roots, MAXROOTS);
+    if (k >= nr) return;
+    const size_t N = (size_t)h * w;
+    const int root = roots[(size_t)f * MAXROOTS + k];
+    int y0 = root / w, x0 = root - y0 * w;
+    if (is_hole) x0 -= 1;
+    ThreshPred nz{cl + f * N, w, h, thr};
+    StatVisitor sv;
+    const int max_steps = 4 * (w + h) + 65536;
+    bool ok = trace_border(nz, x0, y0, is_hole != 0, sv, max_steps);
+    if (!ok) { st[f].overflow = 1; return; }
+    sv.finish();
+    double m00, m10, m01;
+    moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
+    if (m00 < 10.0 || m00 >= 5000.0) return;
+    if (m00 == 0.0) return;
+    double cx = m10 / m00, cy = m01 / m00;
+    int ix = (int)rint(cx), iy = (int)rint(cy);
+    if (nz(ix, iy)) return;  // blobColor = 0: centre pixel must be dark (out-of-image cannot happen for a valid centroid)
+    int bi = atomicAdd(&st[f].n_blobs, 1);
+    if (bi >= MAXB) { st[f].overflow = 1; return; }
+    int doff = atomicAdd(&st[f].n_dists, sv.npts);
+    if (doff + sv.npts > MAXD) { st[f].overflow = 1; blob_d[((size_t)f * MAXB + bi) * 2] = -1; blob_d[((size_t)f * MAXB + bi) * 2 + 1] = 0; }
+    else {
+        DistVisitor dv{cx, cy, dists + (size_t)f * MAXD + doff};
+        trace_border(nz, x0, y0, is_hole != 0, dv, max_steps);
+        blob_d[((size_t)f * MAXB + bi) * 2] = doff;
+        blob_d[((size_t)f * MAXB + bi) * 2 + 1] = sv.npts;
+    }
+    BlobRec &b = blobs[(size_t)f * MAXB + bi];
+    b.x = cx; b.y = cy; b.r = 0;
+    b.key = root;   // discovery position of the border in the raster scan
+}
+
+// radius = (d[(n-1)/2] + d[n/2]) / 2 of the sorted border distances: one wavefront per blob
+__global__ __launch_bounds__(64) void k_blob_median(FrameState *__restrict__ st, BlobRec *__restrict__ blobs,
+                                                    const int *__restrict__ blob_d, const double *__restrict__ dists)
+{
+    const int f = blockIdx.y, bi = blockIdx.x, lane = threadIdx.x;
+    if (bi >= min(st[f].n_blobs, MAXB)) return;
+    int doff = blob_d[((size_t)f * MAXB + bi) * 2], n = blob_d[((size_t)f * MAXB + bi) * 2 + 1];
+    if (doff < 0 || n <= 0) return;
+    const double *d = dists + (size_t)f * MAXD + doff;
+    const int k1 = (n - 1) / 2, k2 = n / 2;
+    double v1 = 0, v2 = 0;
+    for (int i = lane; i < n; i += 64) {
+        double di = d[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            double dj = d[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        if (rank == k1) v1 = di;
+        if (rank == k2) v2 = di;
+    }
+    // exactly one lane holds each value
+    for (int off = 32; off >= 1; off >>= 1) {
+        v1 = fmax(v1, __shfl_xor(v1, off, 64));
+        v2 = fmax(v2, __shfl_xor(v2, off, 64));
+    }
+    if (lane == 0) blobs[(size_t)f * MAXB + bi].r = (v1 + v2) / 2.;
+}
+
+// order this threshold's blobs like cv2.findContours returns contours (latest discovery first) and merge
+// them into the groups (SimpleBlobDetector::detect inner loops); one wavefront per frame
+__global__ __launch_bounds__(64) void k_blob_merge(FrameState *__restrict__ st, const BlobRec *__restrict__ blobs,
+                                                   int *__restrict__ order, Group *__restrict__ groups)
+{
+    __shared__ double sMid[MAXG][3];   // location + radius of each group's middle centre (what the tests read)
+    const int f = blockIdx.x, lane = threadIdx.x;
+    FrameState &S = st[f];
+    const int nb = min(S.n_blobs, MAXB);
+    const BlobRec *B = blobs + (size_t)f * MAXB;
+    int *ord = order + (size_t)f * MAXB;
+    Group *G = groups + (size_t)f * MAXG;
+    for (int i = lane; i < nb; i += 64) {
+        int ki = B[i].key, rank = 0;
+        for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0;
+        ord[rank] = i;
+    }
+    const int ng0 = min(S.n_groups, MAXG);
+    for (int j = lane; j < ng0; j += 64) {
+        const Group &g = G[j];
+        const double *mid = g.c[g.n / 2];
+        sMid[j][0] = mid[0]; sMid[j][1] = mid[1]; sMid[j][2] = mid[2];
+    }
+    __syncthreads();
+    int ng = ng0;
+    for (int q = 0; q < nb; q++) {
+        const BlobRec c = B[ord[q]];
+        int jm = INT_MAX;
+        for (int j0 = 0; j0 < ng0 && jm == INT_MAX; j0 += 64) {
+            int j = j0 + lane;
+            bool match = false;
+            if (j < ng0) {
+                double dx = sMid[j][0] - c.x, dy = sMid[j][1] - c.y;
+                double dist = sqrt(dx * dx + dy * dy);
+                bool isNew = dist >= 10.0 && dist >= sMid[j][2] && dist >= c.r;
+                match = !isNew;
+            }
+            unsigned long long bal = __ballot(match);
+            if (bal) jm = j0 + __ffsll((long long)bal) - 1;
+        }
+        if (lane == 0) {
+            if (jm != INT_MAX) {
+                Group &g = G[jm];   // only lane 0 ever touches the group lists
+                if (g.n < GCAP) {
+                    int k = g.n++;
+                    while (k > 0 && c.r < g.c[k - 1][2]) {
+                        g.c[k][0] = g.c[k - 1][0]; g.c[k][1] = g.c[k - 1][1]; g.c[k][2] = g.c[k - 1][2];
+                        k--;
+                    }
+                    g.c[k][0] = c.x; g.c[k][1] = c.y; g.c[k][2] = c.r;
+                    const double *mid = g.c[g.n / 2];
+                    sMid[jm][0] = mid[0]; sMid[jm][1] = mid[1]; sMid[jm][2] = mid[2];
+                } else S.overflow = 1;
+            } else if (ng < MAXG) {
+                Group &g = G[ng];
+                g.n = 1;
+                g.c[0][0] = c.x; g.c[0][1] = c.y; g.c[0][2] = c.r;
+            } else S.overflow = 1;
+        }
+        if (jm == INT_MAX && ng < MAXG) ng++;
+        __syncthreads();
+    }
+    if (lane == 0) { S.n_groups = ng; S.n_blobs = 0; S.n_dists = 0; }
+}
+
+// groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
+__global__ __launch_bounds__(256) void k_discs(FrameState *__restrict__ st, const Group *__restrict__ groups, int h, int w,
+                                               uint8_t *__restrict__ ext)
+{
+    const int f = blockIdx.y;
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= min(st[f].n_groups, MAXG)) return;
+    const Group &g = groups[(size_t)f * MAXG + gi];
+    if (g.n < 2) return;
+    double sx = 0, sy = 0, nrm = 0;
+    for (int j = 0; j < g.n; j++) { sx += 1.0 * g.c[j][0]; sy += 1.0 * g.c[j][1]; nrm += 1.0; }
+    sx *= (1. / nrm);
+    sy *= (1. / nrm);
+    float kx = (float)sx, ky = (float)sy, ksize = (float)(g.c[g.n / 2][2]) * 2.0f;
+    float radius = ksize / 2;
+    int er = (int)((double)radius + 4);
+    int cx = (int)kx, cy = (int)ky;
+    atomicAdd(&st[f].n_kp, 1);
+    uint8_t *im = ext + (size_t)f * h * w;
+    int err = 0, dx = er, dy = 0, plus = 1, minus = (er << 1) - 1;
+    while (dx >= dy) {
+        int ys[4] = {cy - dy, cy + dy, cy - dx, cy + dx};
+        int xa[4] = {cx - dx, cx - dx, cx - dy, cx - dy};
+        int xb[4] = {cx + dx, cx + dx, cx + dy, cx + dy};
+        for (int q = 0; q < 4; q++) {
+            if (ys[q] < 0 || ys[q] >= h) continue;
+            int x1 = max(xa[q], 0), x2 = min(xb[q], w - 1);
+            for (int x = x1; x <= x2; x++) im[(size_t)ys[q] * w + x] = 255;
+        }
+        dy++;
+        err += plus;
+        plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+// contourArea of every external contour of the disc union; keep the largest (first in OpenCV order on ties)
+__global__ __launch_bounds__(64) void k_region_area(const uint8_t *__restrict__ ext, int h, int w,
+                                                    const int *__restrict__ roots, FrameState *__restrict__ st,
+                                                    unsigned long long *__restrict__ best)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    const size_t N = (size_t)h * w;
+    const int root = roots[(size_t)f * MAXROOTS + k];
+    MaskPred nz{ext + f * N, w, h};
+    StatVisitor sv;
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
+    sv.finish();
+    long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;  // 2 * area, exact
+    if (a2 <= 0) return;
+    // maximise (area, root): the later-discovered contour comes first in OpenCV's list
+    unsigned long long key = ((unsigned long long)a2 << 24) | (unsigned long long)(root & 0xFFFFFF);
+    atomicMax(&best[f], key);
+}
+
+struct HullVisitor {
+    int *lo, *hi;
+    int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
+    __device__ __forceinline__ void point(int x, int y, bool)
+    {
+        lo[x] = min(lo[x], y);
+        hi[x] = max(hi[x], y);
+        minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
+    }
+};
+
+__device__ __forceinline__ long long cross3(int ox, int oy, int ax, int ay, int bx, int by)
+{
+    return (long long)(ax - ox) * (by - oy) - (long long)(ay - oy) * (bx - ox);
+}
+
+__device__ void dev_line(uint8_t *img, int h, int w, int x1, int y1, int x2, int y2)
+{
+    int dx = x2 - x1, dy = y2 - y1;
+    if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
+    int sy = dy < 0 ? -1 : 1;
+    int ady = dy < 0 ? -dy : dy;
+    int x = x1, y = y1;
+    if (ady > dx) {
+        int err = ady - (dx + dx), plus = ady + ady, minus = -(dx + dx);
+        for (int i = 0; i <= ady; i++) {
+            if (x >= 0 && x < w && y >= 0 && y < h) img[(size_t)y * w + x] = 255;
+            int m = err < 0;
+            err += minus + (m ? plus : 0);
+            y += sy;
+            if (m) x += 1;
+        }
+    } else {
+        int err = dx - (ady + ady), plus = dx + dx, minus = -(ady + ady);
+        for (int i = 0; i <= dx; i++) {
+            if (x >= 0 && x < w && y >= 0 && y < h) img[(size_t)y * w + x] = 255;
+            int m = err < 0;
+            err += minus + (m ? plus : 0);
+            x += 1;
+            if (m) y += sy;
+        }
+    }
+}
+
+// hull of the selected contour -> filled polygon (drawContours thickness=-1) + bounding rect
+__global__ __launch_bounds__(256) void k_hull_fill(const uint8_t *__restrict__ ext, int h, int w,
+                                                   const unsigned long long *__restrict__ best, FrameState *__restrict__ st,
+                                                   int *__restrict__ lohi /* n * 2 * w */, int *__restrict__ hull /* n * 4 * w */,
+                                                   uint8_t *__restrict__ mc)
+{
+    const int f = blockIdx.x, t = threadIdx.x;
+    __shared__ int s_nh;
+    const size_t N = (size_t)h * w;
+    FrameState &S = st[f];
+    if (best[f] == 0) {
+        if (t == 0) S.status = CPE_ST_NO_REGION;
+        return;
+    }
+    const int root = (int)(best[f] & 0xFFFFFF);
+    int *lo = lohi + (size_t)f * 2 * w, *hi = lo + w;
+    int *hp = hull + (size_t)f * 4 * w;
+    for (int x = t; x < w; x += 256) { lo[x] = INT_MAX; hi[x] = INT_MIN; }
+    __syncthreads();
+    if (t == 0) {
+        MaskPred nz{ext + f * N, w, h};
+        HullVisitor hv{lo, hi};
+        trace_border(nz, root % w, root / w, false, hv, 8 * (w + h) + (1 << 20));
+        S.rect[0] = hv.minx; S.rect[1] = hv.miny; S.rect[2] = hv.maxx - hv.minx + 1; S.rect[3] = hv.maxy - hv.miny + 1;
+        // monotone chain over columns; points sorted by (x,y): per column first lo then hi
+        int k = 0;
+        for (int x = hv.minx; x <= hv.maxx; x++) {
+            if (lo[x] == INT_MAX) continue;
+            int ys[2] = {lo[x], hi[x]};
+            int cnt = (hi[x] != lo[x]) ? 2 : 1;
+            for (int q = 0; q < cnt; q++) {
+                while (k >= 2 && cross3(hp[2 * (k - 2)], hp[2 * (k - 2) + 1], hp[2 * (k - 1)], hp[2 * (k - 1) + 1], x, ys[q]) <= 0) k--;
+                hp[2 * k] = x; hp[2 * k + 1] = ys[q]; k++;
+            }
+        }
+        int tmin = k + 1;
+        bool first = true;
+        for (int x = hv.maxx; x >= hv.minx; x--) {
+            if (lo[x] == INT_MAX) continue;
+            int ys[2] = {hi[x], lo[x]};
+            int cnt = (hi[x] != lo[x]) ? 2 : 1;
+            for (int q = 0; q < cnt; q++) {
+                if (first) { first = false; continue; }  // skip the very last sorted point (already on the chain)
+                while (k >= tmin && cross3(hp[2 * (k - 2)], hp[2 * (k - 2) + 1], hp[2 * (k - 1)], hp[2 * (k - 1) + 1], x, ys[q]) <= 0) k--;
+                hp[2 * k] = x; hp[2 * k + 1] = ys[q]; k++;
+            }
+        }
+        s_nh = k - 1;
+        S.hull_n = k - 1;
+    }
+    __syncthreads();
+    const int nh = s_nh;
+    uint8_t *out = mc + f * N;
+    if (nh <= 0) return;
+    // outline: Line() between consecutive hull vertices
+    for (int e = t; e < nh; e += 256) {
+        int a = (e + nh - 1) % nh;
+        dev_line(out, h, w, hp[2 * a], hp[2 * a + 1], hp[2 * e], hp[2 * e + 1]);
+    }
+    // scan-line fill (FillEdgeCollection): x in 16.16, left ceil / right floor, rows [ymin, ymax)
+    const int ymin = S.rect[1], ymax = min(S.rect[1] + S.rect[3] - 1, h);
+    for (int y = ymin + t; y < ymax; y += 256) {
+        long long xs[8];
+        int na = 0;
+        for (int e = 0; e < nh && na < 8; e++) {
+            int a = (e + nh - 1) % nh;
+            long long p0x = (long long)hp[2 * a] << 16, p1x = (long long)hp[2 * e] << 16;
+            int p0y = hp[2 * a + 1], p1y = hp[2 * e + 1];
+            if (p0y == p1y) continue;
+            int ey0, ey1;
+            long long ex;
+            if (p0y < p1y) { ey0 = p0y; ey1 = p1y; ex = p0x; }
+            else { ey0 = p1y; ey1 = p0y; ex = p1x; }
+            if (!(ey0 <= y && y < ey1)) continue;
+            long long dx = (p1x - p0x) / (p1y - p0y);
+            xs[na++] = ex + (long long)(y - ey0) * dx;
+        }
+        for (int a = 1; a < na; a++) {
+            long long kx = xs[a];
+            int b = a - 1;
+            while (b >= 0 && xs[b] > kx) { xs[b + 1] = xs[b]; b--; }
+            xs[b + 1] = kx;
+        }
+        if (y < 0) continue;
+        for (int a = 0; a + 1 < na; a += 2) {
+            int x1 = (int)((xs[a] + 65535) >> 16), x2 = (int)(xs[a + 1] >> 16);
+            if (x1 < w && x2 >= 0) {
+                x1 = max(x1, 0);
+                x2 = min(x2, w - 1);
+                for (int x = x1; x <= x2; x++) out[(size_t)y * w + x] = 255;
+            }
+        }
+    }
+}
+
+__global__ void k_region_reset(FrameState *st, int n, unsigned long long *best)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    st[f].n_blobs = 0; st[f].n_dists = 0; st[f].n_groups = 0; st[f].n_kp = 0;
+    best[f] = 0;
+}
+
+}  // namespace
+
+
+int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s)
+{
+    const size_t N = (size_t)h * w, total = N * n;
+    ClaheGeom g;
+    g.tilesX = 4; g.tilesY = 4;
+    g.ew = (w % 4 == 0 && h % 4 == 0) ? w : w + (4 - (w % 4));
+    g.eh = (w % 4 == 0 && h % 4 == 0) ? h : h + (4 - (h % 4));
+    g.tw = g.ew / 4; g.th = g.eh / 4;
+    int tileTotal = g.tw * g.th;
+    g.clipLimit = 0;
+    if (clip > 0.0) { g.clipLimit = (int)(clip * tileTotal / 256); if (g.clipLimit < 1) g.clipLimit = 1; }
+    g.lutScale = (float)255 / tileTotal;
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
+    (void)hipMemsetAsync(B.hist, 0, (size_t)n * 16 * 256 * sizeof(unsigned int), s);
+    const int strips = 8;
+    hipLaunchKernelGGL(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
+    hipLaunchKernelGGL(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
+    CPE_CHECK_LAUNCH("clahe");
+    for (int thr = 50; thr < 220; thr += 10) {
+        int rc;
+        // bright components: outer borders
+        if ((rc = ccl_label(B.cl, n, h, w, thr, 0, 1, B.lab, s)) != CPE_OK) return rc;
+        if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
+        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, st, B.blobs,
+                           B.blob_d, B.dists);
+        // enclosed dark components: hole borders
+        if ((rc = ccl_label(B.cl, n, h, w, thr, 1, 0, B.lab, s)) != CPE_OK) return rc;
+        if ((rc = ccl_collect(B.lab, n, h, w, true, B.touch, B.roots, st, s)) != CPE_OK) return rc;
+        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, st, B.blobs,
+                           B.blob_d, B.dists);
+        hipLaunchKernelGGL(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
+        hipLaunchKernelGGL(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
+        CPE_CHECK_LAUNCH("blob threshold pass");
+    }
+    (void)hipMemsetAsync(B.ext, 0, total, s);
+    (void)hipMemsetAsync(B.mc, 0, total, s);
+    hipLaunchKernelGGL(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
+    int rc;
+    if ((rc = ccl_label(B.ext, n, h, w, 0, 0, 1, B.lab, s)) != CPE_OK) return rc;
+    if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
+    hipLaunchKernelGGL(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.ext, h, w, B.roots, st, B.best);
+    hipLaunchKernelGGL(k_hull_fill, dim3(n), dim3(256), 0, s, B.ext, h, w, B.best, st, B.lohi, B.hull, B.mc);
+    CPE_CHECK_LAUNCH("region hull");
+    return CPE_OK;
+}
+
+}  // namespace cpe

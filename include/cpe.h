@@ -68,6 +68,39 @@ CPE_API int32_t cpe_preprocess_batch(const uint8_t *gray, int32_t n, int32_t h, 
                              void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * detect_grid(input_img) for a batch of n grey frames (python_grid_detection_cylinder.py:68-112 ->
+ * util_cylinder.py stages 1-6): gray u8[n,h,w] (the 2-D array makePyGridPts.m:26 passes; a BGR frame
+ * with three identical channels is the same image) ->
+ *   xy f64[n,CPE_MAXP,2], id i32[n,CPE_MAXP,2] = (col,row), n_pts i32[n], center f64[n,2]:
+ *   exactly the content make_json serialises (util_cylinder.py:1674-1727): points with col >= 0 sorted
+ *   by (col,row), and the centre point;
+ *   status i32[n]: CPE_ST_* (the places where the reference raises inside detect_grid and returns None).
+ * ws: cpe_detect_workspace_bytes(n,h,w) bytes of 256-byte aligned device scratch.  64 <= h,w <= 4096.
+ */
+CPE_API size_t cpe_detect_workspace_bytes(int32_t n, int32_t h, int32_t w);
+CPE_API int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t h, int32_t w, void *ws, size_t ws_bytes,
+                                      double *xy, int32_t *id, int32_t *n_pts, double *center, int32_t *status,
+                                      void *stream);
+
+/* Where an intermediate of the last cpe_detect_grid_batch call lives inside the workspace (for
+ * stage-by-stage parity tests and debugging): plane-major, frame f at offset + f * bytes_per_frame. */
+#define CPE_PLANE_BINARY 0        /* u8[h,w]  load_and_preprocess_image -> binary_img */
+#define CPE_PLANE_HMASK 1         /* u8[h,w]  extract_joints -> horizontal_mask */
+#define CPE_PLANE_VMASK 2         /* u8[h,w]  extract_joints -> vertical_mask */
+#define CPE_PLANE_MASK_CONTOUR 3  /* u8[h,w]  detect_largest_blob -> mask_contour */
+#define CPE_PLANE_ROI_H 4         /* u8[h,w]  mask_roi_around_center -> mask_roi_h */
+#define CPE_PLANE_ROI_V 5
+#define CPE_PLANE_EXP_H 6         /* u8[h,w]  expands_line_roi -> horizontal_expanded */
+#define CPE_PLANE_EXP_V 7
+#define CPE_PLANE_JOINTS 8        /* i32[4096,2] cylinder_centroids in contour order */
+#define CPE_PLANE_STATE 9         /* per-frame state record (see csrc/cpe_dev.h FrameState) */
+#define CPE_PLANE_CLAHE 10        /* u8[h,w]  CLAHE'd L channel */
+#define CPE_PLANE_BLUR19 11       /* u8[h,w] */
+#define CPE_PLANE_BLUR7 12        /* u8[h,w] */
+CPE_API int32_t cpe_detect_workspace_plane(int32_t n, int32_t h, int32_t w, int32_t plane, size_t *offset,
+                                           size_t *bytes_per_frame);
+
+/* ------------------------------------------------------------------------------------------
  * Grid-point tables.  One table per image: xy f64[n,CPE_MAXP,2] pixel coordinates, id i32[n,CPE_MAXP,2]
  * (col,row) grid indices, cnt i32[n] -- the padded form of the reference's N x 4 matrix
  * [x y colIdx rowIdx] (makePyGridPts.m:39-41, pointsStruct2mat.m:16).

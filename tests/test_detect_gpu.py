@@ -1,0 +1,106 @@
+"""Image half on the GPU (through cpe_detect_grid_batch) vs the oracle, stage by stage and end to end.
+Integer / byte stages: bit-exact.  Point coordinates: the kernels run the oracle's f64 operation order,
+so they are compared for equality as well (stated tolerance 0; BASELINE allows 1e-3 px)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _frames(h, w, n, seed):
+    from cpe_amd import synth
+    b = synth.render_batch(n, h, w, seed=seed, with_gt=False)
+    return torch.cat([b['left'], b['right']])
+
+
+def _compare(cpe, orc, gpu, frames, check_planes=True):
+    from oracle import stages as S
+    det = cpe.api.detect_grid_batch(frames.to(gpu))
+    torch.cuda.synchronize()
+    ws = det['ws']
+    planes = {k: ws.plane(k).cpu().numpy() for k in ('binary', 'hmask', 'vmask', 'mask_contour', 'roi_h', 'roi_v',
+                                                     'exp_h', 'exp_v', 'clahe')} if check_planes else {}
+    joints = ws.plane('joints').cpu().numpy()
+    state = ws.state()
+    npy = frames.numpy()
+    n_ok = 0
+    for i in range(npy.shape[0]):
+        ref = S.detect_grid(npy[i], debug=True)
+        tag = f'frame {i}'
+        if check_planes:
+            assert np.array_equal(planes['binary'][i], ref['binary']), tag
+            assert np.array_equal(planes['hmask'][i], ref['hmask']), tag
+            assert np.array_equal(planes['vmask'][i], ref['vmask']), tag
+            assert np.array_equal(planes['clahe'][i], S.clahe(S.lab_l(npy[i]))), tag
+            assert np.array_equal(planes['mask_contour'][i], ref['mask_contour']), tag
+        assert int(det['status'][i]) == ref['status'], (tag, state[i], ref['status'])
+        if ref['status'] in (1,):
+            continue
+        assert (state[i]['rect0'], state[i]['rect1'], state[i]['rect2'], state[i]['rect3']) == tuple(ref['rect']), tag
+        assert state[i]['n_kp'] == ref['n_keypoints'], tag
+        if ref['status'] == 2:
+            continue
+        assert state[i]['r0'] == ref['r0'] and (state[i]['spot0'], state[i]['spot1'], state[i]['spot2'], state[i]['spot3']) == tuple(ref['spot']), tag
+        assert state[i]['n_joints'] == ref['n_cyl_joints'], tag
+        if check_planes:
+            for k in ('roi_h', 'roi_v', 'exp_h', 'exp_v'):
+                assert np.array_equal(planes[k][i], ref[k]), (tag, k, int((planes[k][i] != ref[k]).sum()))
+        if ref['status'] != 0:
+            continue
+        n_ok += 1
+        m = int(det['n'][i])
+        assert m == len(ref['xy']), tag
+        assert np.array_equal(det['id'][i, :m].cpu().numpy(), ref['id']), tag
+        assert np.array_equal(det['center'][i].cpu().numpy(), ref['center']), tag
+        got = det['xy'][i, :m].cpu().numpy()
+        assert np.array_equal(got, ref['xy']), (tag, np.abs(got - ref['xy']).max())
+    return n_ok
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w,seed', [(480, 640, 0), (600, 800, 4)])
+def test_detect_small_frames_stage_by_stage(cpe, orc, gpu, h, w, seed):
+    n_ok = _compare(cpe, orc, gpu, _frames(h, w, 2, seed))
+    assert n_ok >= 2
+
+
+@pytest.mark.gpu
+def test_detect_full_size(cpe, orc, gpu):
+    from cpe_amd import synth
+    b = synth.render_batch(2, 1200, 1920, seed=11, device='cuda', with_gt=False)
+    frames = torch.cat([b['left'], b['right']]).cpu()
+    n_ok = _compare(cpe, orc, gpu, frames)
+    assert n_ok == 4
+
+
+@pytest.mark.gpu
+def test_detect_failure_statuses(cpe, orc, gpu):
+    """frames on which the reference raises inside detect_grid: all-dark (no blob region), grid without the
+    saturated spot, pure noise -- the batch is never aborted, every frame gets the oracle's status."""
+    rng = np.random.default_rng(3)
+    f = _frames(480, 640, 1, 2).numpy().copy()
+    dark = np.full((480, 640), 7, np.uint8)
+    nospot = f[0].copy(); nospot[nospot > 235] = 200
+    noise = rng.integers(0, 60, size=(480, 640), dtype=np.uint8)
+    frames = torch.from_numpy(np.stack([dark, nospot, noise, f[1]]))
+    _compare(cpe, orc, gpu, frames, check_planes=False)
+
+
+@pytest.mark.gpu
+def test_reference_signature_and_json(cpe, orc, gpu):
+    import json
+    from oracle import stages as S
+    f = _frames(480, 640, 1, 0).numpy()
+    out = cpe.api.detect_grid(f[0])
+    assert out is not None and len(out) == 4
+    col_img, result_json, rows_updated, cols_updated = out
+    assert col_img.shape == (480, 640, 3) and col_img.dtype == np.uint8
+    d = json.loads(result_json)
+    assert list(d.keys()) == ['center_point', 'points'] and list(d['points'][0].keys()) == ['id', 'x', 'y']
+    ref = S.detect_grid(f[0])
+    assert [p['id'] for p in d['points']] == ref['id'].tolist()
+    assert np.array_equal(np.array([[p['x'], p['y']] for p in d['points']]), ref['xy'])
+    assert all(p['id'][0] >= 0 for p in d['points'])                                 # remove_minus_labels
+    assert [tuple(p['id']) for p in d['points']] == sorted(tuple(p['id']) for p in d['points'])   # make_json sort
+    bgr = np.repeat(f[0][..., None], 3, axis=2)                                       # cv2.imread-style grey BGR
+    assert cpe.api.detect_grid(bgr)[1] == result_json
+    assert cpe.api.detect_grid(np.full((480, 640), 5, np.uint8)) is None              # reference: prints + None
