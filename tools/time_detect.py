@@ -1,7 +1,7 @@
 """quick timing of the detect + fit pipeline (run under rocprofv3 --stats for the per-kernel table)"""
 import sys, time
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cpe_amd
 from cpe_amd import synth, api, fit
 
