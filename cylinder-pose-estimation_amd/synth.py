@@ -28,7 +28,8 @@ class Scene:
     depth: tuple = (330.0, 400.0)   # mm, axis distance
     tilt_deg: float = 8.0           # axis tilt about camera z and x, uniform +-
     pitch_px: float = 34.0          # grid pitch in the image centre
-    half_lines: int = None          # lines -N..N per direction; default from the image size
+    half_lines: int = None          # vertical grid lines -N..N (across the cylinder); default from the image size
+    half_lines_v: int = None        # horizontal grid lines -Nv..Nv (along the axis)
     line_sigma: float = 1.6         # px
     peak: tuple = (185.0, 230.0)
     background: tuple = (6.0, 16.0)
@@ -40,6 +41,8 @@ class Scene:
             self.focal = 1.55 * self.w
         if self.half_lines is None:
             self.half_lines = max(3, int(0.32 * min(self.w * 0.55, self.h) / self.pitch_px))
+        if self.half_lines_v is None:
+            self.half_lines_v = max(3, int(0.43 * self.h / self.pitch_px))
 
 
 def _rot(ax, ay, az):
@@ -98,11 +101,14 @@ def _cyl_hit(o, d, c, a, R):
     return s, hit & (s > 0)
 
 
-def _render_view(scene, K, Tcam, Tp, fp, delta, device, gen):
-    """render one view for all frames. Tcam: cam1 -> this camera (4x4). returns u8 [n,h,w]"""
+def _render_view(scene, K, Tcam, Tp, fp, delta, device, gen, chunk=None):
+    """render one view for all frames (batched over `chunk` frames per torch op). Tcam: cam1 -> this camera (4x4).
+    returns u8 [n,h,w]"""
     n = fp['org'].shape[0]
     h, w = scene.h, scene.w
     dt = torch.float32
+    if chunk is None:
+        chunk = 8 if torch.device(device).type == 'cuda' else 1
     Kinv = torch.tensor(np.linalg.inv(K), dtype=dt, device=device)
     Rc = torch.tensor(Tcam[:3, :3], dtype=dt, device=device)
     tc = torch.tensor(Tcam[:3, 3], dtype=dt, device=device)
@@ -112,51 +118,56 @@ def _render_view(scene, K, Tcam, Tp, fp, delta, device, gen):
                             indexing='ij')
     pix = torch.stack([xs, ys, torch.ones_like(xs)], -1)           # [h,w,3]
     d_cam = pix @ Kinv.T                                            # ray dirs in this camera
-    d1 = d_cam @ Rc                                                 # -> cam-1 coords (R^T applied as row-vector @ R)
+    d1 = (d_cam @ Rc).unsqueeze(0)                                  # -> cam-1 coords, [1,h,w,3]
     o1 = -(Rc.T @ tc)                                               # camera centre in cam-1 coords
     Op = -(Rp.T @ tp)                                               # projector centre in cam-1 coords
     out = torch.empty((n, h, w), dtype=torch.uint8, device=device)
     N = scene.half_lines
-    for i in range(n):
-        c = torch.tensor(fp['org'][i], dtype=dt, device=device)
-        a = torch.tensor(fp['dir'][i], dtype=dt, device=device)
+    Nv = scene.half_lines_v
+    for i0 in range(0, n, chunk):
+        i1 = min(n, i0 + chunk)
+        B = i1 - i0
+        c = torch.tensor(fp['org'][i0:i1], dtype=dt, device=device).view(B, 1, 1, 3)
+        a = torch.tensor(fp['dir'][i0:i1], dtype=dt, device=device).view(B, 1, 1, 3)
+        peak = torch.tensor(fp['peak'][i0:i1], dtype=dt, device=device).view(B, 1, 1)
+        bg = torch.tensor(fp['bg'][i0:i1], dtype=dt, device=device).view(B, 1, 1)
+        spot_r = torch.tensor(fp['spot'][i0:i1], dtype=dt, device=device).view(B, 1, 1)
         s, hit = _cyl_hit(o1, d1, c, a, scene.radius)
-        X = o1 + s.unsqueeze(-1) * d1                                # surface point, cam-1 coords
+        X = o1 + s.unsqueeze(-1) * d1                                # surface point, cam-1 coords [B,h,w,3]
         wv = X - c
-        nrm = wv - (wv * a).sum(-1, keepdim=True) * a
-        nrm = nrm / scene.radius
+        nrm = (wv - (wv * a).sum(-1, keepdim=True) * a) / scene.radius
         toP = Op - X
-        lit = hit & ((nrm * toP).sum(-1) > 0)
-        cosi = ((nrm * toP).sum(-1) / toP.norm(dim=-1)).clamp(0, 1)
+        ndot = (nrm * toP).sum(-1)
+        lit = hit & (ndot > 0)
+        cosi = (ndot / toP.norm(dim=-1)).clamp(0, 1)
         Xp = X @ Rp.T + tp
         pa = Xp[..., 0] / Xp[..., 2] / delta                         # grid coordinates (integers on lines)
         pb = Xp[..., 1] / Xp[..., 2] / delta
-        img = torch.full((h, w), float(fp['bg'][i]), dtype=dt, device=device)
-        amp = float(fp['peak'][i]) * (0.45 + 0.55 * cosi)
-        for q, other in ((pa, pb), (pb, pa)):
-            gy_, gx_ = torch.gradient(q)
+        del X, wv, nrm, toP, Xp
+        img = bg.expand(B, h, w).clone()
+        amp = peak * (0.45 + 0.55 * cosi)
+        jac = []
+        for q, other, nq, no in ((pa, pb, N, Nv), (pb, pa, Nv, N)):
+            gy_, gx_ = torch.gradient(q, dim=(1, 2))
             gnorm = torch.sqrt(gx_ * gx_ + gy_ * gy_).clamp_min(1e-6)
+            jac.append(gnorm)
             r = torch.round(q)
             dist = (q - r).abs() / gnorm                             # px distance to the nearest grid line
-            on = lit & (r.abs() <= N) & (other.abs() <= N + 0.35) & (gnorm < 0.5)
+            on = lit & (r.abs() <= nq) & (other.abs() <= no + 0.35) & (gnorm < 0.5)
             img = img + torch.where(on, amp * torch.exp(-0.5 * (dist / scene.line_sigma) ** 2), torch.zeros_like(img))
         # zero-order spot at (0,0)
-        gya, gxa = torch.gradient(pa)
-        gyb, gxb = torch.gradient(pb)
-        ja = torch.sqrt(gxa * gxa + gya * gya).clamp_min(1e-6)
-        jb = torch.sqrt(gxb * gxb + gyb * gyb).clamp_min(1e-6)
-        rr = torch.sqrt((pa / ja) ** 2 + (pb / jb) ** 2)
-        spot = torch.where(lit, 400.0 * torch.sigmoid((float(fp['spot'][i]) - rr) * 1.2), torch.zeros_like(img))
-        img = img + spot
-        img = img + scene.noise_sigma * torch.randn((h, w), generator=gen, device=device, dtype=dt)
-        out[i] = img.round().clamp(0, 255).to(torch.uint8)
+        rr = torch.sqrt((pa / jac[0]) ** 2 + (pb / jac[1]) ** 2)
+        img = img + torch.where(lit, 400.0 * torch.sigmoid((spot_r - rr) * 1.2), torch.zeros_like(img))
+        for k in range(B):
+            img[k] += scene.noise_sigma * torch.randn((h, w), generator=gen, device=device, dtype=dt)
+        out[i0:i1] = img.round().clamp(0, 255).to(torch.uint8)
     return out
 
 
 def ground_truth(scene: Scene, K1, K2, T21, Tp, fp, delta):
     """per frame: dict(idx [m,2] (col,row) projector indices, X [m,3], uv1 [m,2], uv2 [m,2])"""
-    N = scene.half_lines
-    ii, jj = np.meshgrid(np.arange(-N, N + 1), np.arange(-N, N + 1), indexing='ij')
+    N, Nv = scene.half_lines, scene.half_lines_v
+    ii, jj = np.meshgrid(np.arange(-N, N + 1), np.arange(-Nv, Nv + 1), indexing='ij')
     rays_p = np.stack([ii.ravel() * delta, jj.ravel() * delta, np.ones(ii.size)], 1)
     Rp, tp = Tp[:3, :3], Tp[:3, 3]
     Op = -Rp.T @ tp
