@@ -22,7 +22,7 @@ __device__ __forceinline__ bool pred(const uint8_t *img, size_t i, int thr, int 
 }
 
 __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ img, int rows_total, int h, int w,
-                                                  int thr, int invert, int *__restrict__ L)
+                                                  int thr, int invert, int *__restrict__ L, int *__restrict__ cnt)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
         unsigned long long b = __ballot(in);
         unsigned long long prev = (b << 1) | (unsigned long long)carry_in;
         unsigned long long starts = b & ~prev;
+        if (cnt && x < w) cnt[base + x] = 0;
         if (in) {
             unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
             int sx = m ? (x0 + 63 - __clzll(m)) : carry_start;
@@ -92,6 +93,48 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(size_t total, size_t N, int
     L[gi] = uf_find(L + f * N, v);
 }
 
+// per-component pixel counts, aggregated per wavefront before the atomic (one add per distinct root
+// in a wave).  interior_only: count only pixels whose 8 neighbours are all in the set and inside the image.
+// Used as exact prune bounds for the blob detector: a hole of >= 5000 pixels has polygon area >= 5000, and
+// a bright component with >= 5000 interior pixels has outer-polygon area >= 5000 (border-polygon edges
+// only cross the unit squares of their own end-point pixels).
+__global__ __launch_bounds__(256) void k_ccl_count(const uint8_t *__restrict__ img, const int *__restrict__ L,
+                                                   size_t total, int h, int w, int thr, int invert, int interior_only,
+                                                   int *__restrict__ cnt)
+{
+    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N = (size_t)h * w;
+    int root = -1;
+    size_t f = 0;
+    if (gi < total) {
+        f = gi / N;
+        const int i = (int)(gi - f * N);
+        root = L[gi];
+        if (root >= 0 && interior_only) {
+            const int y = i / w, x = i - y * w;
+            const uint8_t *im = img + f * N;
+            bool inter = x > 0 && x < w - 1 && y > 0 && y < h - 1;
+            if (inter) {
+                inter = pred(im, i - w - 1, thr, invert) && pred(im, i - w, thr, invert) && pred(im, i - w + 1, thr, invert) &&
+                        pred(im, i - 1, thr, invert) && pred(im, i + 1, thr, invert) && pred(im, i + w - 1, thr, invert) &&
+                        pred(im, i + w, thr, invert) && pred(im, i + w + 1, thr, invert);
+            }
+            if (!inter) root = -1;
+        }
+    }
+    // key = frame-local root; lanes of one wave may straddle two frames: include the frame in the key
+    long long key = root >= 0 ? (long long)(f * N) + root : -1;
+    unsigned long long active = __ballot(key >= 0);
+    const int lane = threadIdx.x & 63;
+    while (active) {
+        int leader = __ffsll((long long)active) - 1;
+        long long lk = __shfl(key, leader, 64);
+        unsigned long long same = __ballot(key == lk) & active;
+        if (lane == leader) atomicAdd(&cnt[lk], __popcll(same));
+        active &= ~same;
+    }
+}
+
 // frame-connected background components: touch[root] = 1
 __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, int n, int h, int w, uint8_t *__restrict__ touch)
 {
@@ -134,12 +177,28 @@ __global__ void k_reset_roots(FrameState *st, int n)
 }  // namespace
 
 // labels for the set {(img > thr) != invert}; conn8 selects 8- vs 4-connectivity
+int ccl_label_count(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *cnt,
+                    int interior_only, hipStream_t s)
+{
+    const size_t N = (size_t)h * w, total = N * n;
+    const int rows = n * h;
+    CPE_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L, cnt);
+    hipLaunchKernelGGL(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
+                       conn8, L);
+    hipLaunchKernelGGL(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);
+    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, L, total, h, w, thr, invert,
+                       interior_only, cnt);
+    CPE_CHECK_LAUNCH("ccl_label_count");
+    return CPE_OK;
+}
+
 int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s)
 {
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L);
+    hipLaunchKernelGGL(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L, (int *)nullptr);
     hipLaunchKernelGGL(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
                        conn8, L);
     hipLaunchKernelGGL(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);

@@ -130,7 +130,7 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     FrameState *st = PL(FrameState, P_STATE);
     RegionBuffers R;
     R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
-    R.lab = PL(int, P_LAB0); R.roots = PL(int, P_ROOTS); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
+    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
     R.blobs = PL(BlobRec, P_BLOBS); R.blob_d = PL(int, P_BLOB_D); R.order = PL(int, P_ORDER); R.dists = PL(double, P_DISTS);
     R.groups = PL(Group, P_GROUPS); R.best = PL(unsigned long long, P_BEST); R.lohi = PL(int, P_LOHI); R.hull = PL(int, P_HULL);
     MaskBuffers M;

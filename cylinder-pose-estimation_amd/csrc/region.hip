@@ -17,6 +17,8 @@ namespace cpe {
 int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
 int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *touch, int *roots, FrameState *st,
                 hipStream_t s);
+int ccl_label_count(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *cnt,
+                    int interior_only, hipStream_t s);
 
 namespace {
 
@@ -129,9 +131,9 @@ struct DistVisitor {
 
 // one thread per component: outer border (is_hole = 0) or hole border (is_hole = 1)
 __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int thr, int is_hole,
-                                                   const int *__restrict__ roots, FrameState *__restrict__ st,
-                                                   BlobRec *__restrict__ blobs, int *__restrict__ blob_d,
-                                                   double *__restrict__ dists)
+                                                   const int *__restrict__ roots, const int *__restrict__ cnt,
+                                                   FrameState *__restrict__ st, BlobRec *__restrict__ blobs,
+                                                   int *__restrict__ blob_d, double *__restrict__ dists)
 {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     if (k >= nr) return;
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
+    if (cnt[f * N + root] >= 5000) return;   // exact prune: polygon area >= pixel count bound >= maxArea
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
     ThreshPred nz{cl + f * N, w, h, thr};
@@ -496,14 +499,14 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     for (int thr = 50; thr < 220; thr += 10) {
         int rc;
         // bright components: outer borders
-        if ((rc = ccl_label(B.cl, n, h, w, thr, 0, 1, B.lab, s)) != CPE_OK) return rc;
+        if ((rc = ccl_label_count(B.cl, n, h, w, thr, 0, 1, B.lab, B.cnt, 1, s)) != CPE_OK) return rc;
         if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
-        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, st, B.blobs,
+        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
                            B.blob_d, B.dists);
         // enclosed dark components: hole borders
-        if ((rc = ccl_label(B.cl, n, h, w, thr, 1, 0, B.lab, s)) != CPE_OK) return rc;
+        if ((rc = ccl_label_count(B.cl, n, h, w, thr, 1, 0, B.lab, B.cnt, 0, s)) != CPE_OK) return rc;
         if ((rc = ccl_collect(B.lab, n, h, w, true, B.touch, B.roots, st, s)) != CPE_OK) return rc;
-        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, st, B.blobs,
+        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
                            B.blob_d, B.dists);
         hipLaunchKernelGGL(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
         hipLaunchKernelGGL(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
