@@ -93,6 +93,23 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(size_t total, size_t N, int
     L[gi] = uf_find(L + f * N, v);
 }
 
+// frame-connected background components: touch[root] = 1
+__global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, int n, int h, int w, uint8_t *__restrict__ touch)
+{
+    const int per = 2 * w + 2 * h;
+    int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n * per) return;
+    int f = gi / per, k = gi - f * per;
+    int x, y;
+    if (k < w) { x = k; y = 0; }
+    else if (k < 2 * w) { x = k - w; y = h - 1; }
+    else if (k < 2 * w + h) { x = 0; y = k - 2 * w; }
+    else { x = w - 1; y = k - 2 * w - h; }
+    size_t N = (size_t)h * w;
+    int v = L[f * N + (size_t)y * w + x];
+    if (v >= 0) touch[f * N + v] = 1;
+}
+
 // per-component pixel counts, aggregated per wavefront before the atomic (one add per distinct root
 // in a wave).  interior_only: count only pixels whose 8 neighbours are all in the set and inside the image.
 // Used as exact prune bounds for the blob detector: a hole of >= 5000 pixels has polygon area >= 5000, and
@@ -100,7 +117,7 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(size_t total, size_t N, int
 // only cross the unit squares of their own end-point pixels).
 __global__ __launch_bounds__(256) void k_ccl_count(const uint8_t *__restrict__ img, const int *__restrict__ L,
                                                    size_t total, int h, int w, int thr, int invert, int interior_only,
-                                                   int *__restrict__ cnt)
+                                                   const uint8_t *__restrict__ touch, int *__restrict__ cnt)
 {
     size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t N = (size_t)h * w;
@@ -110,6 +127,7 @@ __global__ __launch_bounds__(256) void k_ccl_count(const uint8_t *__restrict__ i
         f = gi / N;
         const int i = (int)(gi - f * N);
         root = L[gi];
+        if (root >= 0 && touch && touch[f * N + root]) root = -1;   // frame-connected background: never a hole
         if (root >= 0 && interior_only) {
             const int y = i / w, x = i - y * w;
             const uint8_t *im = img + f * N;
@@ -133,23 +151,6 @@ __global__ __launch_bounds__(256) void k_ccl_count(const uint8_t *__restrict__ i
         if (lane == leader) atomicAdd(&cnt[lk], __popcll(same));
         active &= ~same;
     }
-}
-
-// frame-connected background components: touch[root] = 1
-__global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, int n, int h, int w, uint8_t *__restrict__ touch)
-{
-    const int per = 2 * w + 2 * h;
-    int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= n * per) return;
-    int f = gi / per, k = gi - f * per;
-    int x, y;
-    if (k < w) { x = k; y = 0; }
-    else if (k < 2 * w) { x = k - w; y = h - 1; }
-    else if (k < 2 * w + h) { x = 0; y = k - 2 * w; }
-    else { x = w - 1; y = k - 2 * w - h; }
-    size_t N = (size_t)h * w;
-    int v = L[f * N + (size_t)y * w + x];
-    if (v >= 0) touch[f * N + v] = 1;
 }
 
 // roots -> per-frame list (order arbitrary; consumers sort or are order-independent)
@@ -178,7 +179,7 @@ __global__ void k_reset_roots(FrameState *st, int n)
 
 // labels for the set {(img > thr) != invert}; conn8 selects 8- vs 4-connectivity
 int ccl_label_count(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *cnt,
-                    int interior_only, hipStream_t s)
+                    int interior_only, uint8_t *touch, hipStream_t s)
 {
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
@@ -187,8 +188,13 @@ int ccl_label_count(const uint8_t *img, int n, int h, int w, int thr, int invert
     hipLaunchKernelGGL(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
                        conn8, L);
     hipLaunchKernelGGL(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);
+    if (touch) {
+        (void)hipMemsetAsync(touch, 0, total, s);
+        int per = 2 * w + 2 * h;
+        hipLaunchKernelGGL(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, L, n, h, w, touch);
+    }
     hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, L, total, h, w, thr, invert,
-                       interior_only, cnt);
+                       interior_only, (const uint8_t *)touch, cnt);
     CPE_CHECK_LAUNCH("ccl_label_count");
     return CPE_OK;
 }
@@ -208,12 +214,12 @@ int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int 
 
 // collect component roots; holes_only: skip components that touch the image frame (needs a zeroed touch plane)
 int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *touch, int *roots, FrameState *st,
-                hipStream_t s)
+                hipStream_t s, bool touch_ready)
 {
     const size_t N = (size_t)h * w, total = N * n;
     CPE_LAUNCH_BEGIN();
     hipLaunchKernelGGL(k_reset_roots, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
-    if (holes_only) {
+    if (holes_only && !touch_ready) {
         (void)hipMemsetAsync(touch, 0, total, s);
         int per = 2 * w + 2 * h;
         hipLaunchKernelGGL(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, L, n, h, w, touch);

@@ -111,16 +111,10 @@ __device__ __forceinline__ void uf_unite(int *L, int a, int b)
 template <class Pred>
 __device__ __forceinline__ unsigned nbr_mask(const Pred &nz, int x, int y)
 {
-    unsigned m = 0;
-    m |= nz(x + 1, y) ? 1u : 0u;
-    m |= nz(x + 1, y - 1) ? 2u : 0u;
-    m |= nz(x, y - 1) ? 4u : 0u;
-    m |= nz(x - 1, y - 1) ? 8u : 0u;
-    m |= nz(x - 1, y) ? 16u : 0u;
-    m |= nz(x - 1, y + 1) ? 32u : 0u;
-    m |= nz(x, y + 1) ? 64u : 0u;
-    m |= nz(x + 1, y + 1) ? 128u : 0u;
-    return m;
+    const bool b0 = nz(x + 1, y), b1 = nz(x + 1, y - 1), b2 = nz(x, y - 1), b3 = nz(x - 1, y - 1);
+    const bool b4 = nz(x - 1, y), b5 = nz(x - 1, y + 1), b6 = nz(x, y + 1), b7 = nz(x + 1, y + 1);
+    return (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u) | (b4 ? 16u : 0u) | (b5 ? 32u : 0u) |
+           (b6 ? 64u : 0u) | (b7 ? 128u : 0u);
 }
 
 template <class Pred, class Visitor>
@@ -165,7 +159,11 @@ struct MaskPred {
     int w, h;
     __device__ __forceinline__ bool operator()(int x, int y) const
     {
-        return x >= 0 && x < w && y >= 0 && y < h && m[(size_t)y * w + x] != 0;
+        // unconditional load from the clamped address: lets the 8 neighbour loads of one border step issue together
+        const bool inb = (unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h;
+        const int cx = min(max(x, 0), w - 1), cy = min(max(y, 0), h - 1);
+        const uint8_t v = m[(size_t)cy * w + cx];
+        return inb & (v != 0);
     }
 };
 struct ThreshPred {  // binarised = img > t
@@ -173,7 +171,10 @@ struct ThreshPred {  // binarised = img > t
     int w, h, t;
     __device__ __forceinline__ bool operator()(int x, int y) const
     {
-        return x >= 0 && x < w && y >= 0 && y < h && (int)m[(size_t)y * w + x] > t;
+        const bool inb = (unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h;
+        const int cx = min(max(x, 0), w - 1), cy = min(max(y, 0), h - 1);
+        const int v = m[(size_t)cy * w + cx];
+        return inb & (v > t);
     }
 };
 

@@ -13,7 +13,7 @@ namespace cpe {
 
 int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
 int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *touch, int *roots, FrameState *st,
-                hipStream_t s);
+                hipStream_t s, bool touch_ready = false);
 
 namespace {
 

@@ -16,9 +16,9 @@ namespace cpe {
 
 int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
 int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *touch, int *roots, FrameState *st,
-                hipStream_t s);
+                hipStream_t s, bool touch_ready = false);
 int ccl_label_count(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *cnt,
-                    int interior_only, hipStream_t s);
+                    int interior_only, uint8_t *touch, hipStream_t s);
 
 namespace {
 
@@ -499,13 +499,13 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     for (int thr = 50; thr < 220; thr += 10) {
         int rc;
         // bright components: outer borders
-        if ((rc = ccl_label_count(B.cl, n, h, w, thr, 0, 1, B.lab, B.cnt, 1, s)) != CPE_OK) return rc;
+        if ((rc = ccl_label_count(B.cl, n, h, w, thr, 0, 1, B.lab, B.cnt, 1, nullptr, s)) != CPE_OK) return rc;
         if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
         hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
                            B.blob_d, B.dists);
         // enclosed dark components: hole borders
-        if ((rc = ccl_label_count(B.cl, n, h, w, thr, 1, 0, B.lab, B.cnt, 0, s)) != CPE_OK) return rc;
-        if ((rc = ccl_collect(B.lab, n, h, w, true, B.touch, B.roots, st, s)) != CPE_OK) return rc;
+        if ((rc = ccl_label_count(B.cl, n, h, w, thr, 1, 0, B.lab, B.cnt, 0, B.touch, s)) != CPE_OK) return rc;
+        if ((rc = ccl_collect(B.lab, n, h, w, true, B.touch, B.roots, st, s, true)) != CPE_OK) return rc;
         hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
                            B.blob_d, B.dists);
         hipLaunchKernelGGL(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
