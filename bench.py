@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: frames/sec for (grid-detect + cylinder fit) on a 1920x1200 batch.
+
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--chunk C]
+
+A "step" is one pass of the whole hot path (detect_grid on both images of every stereo frame,
+chooseIdx + triangulate, fitCylinderWPts3 Nelder-Mead, applyCylParamsPrior) over one batch of F synthetic
+frames per GPU, inputs resident in HBM before the timed region.  Default F = 4096 = BASELINE.json
+configs[2] ("4096-frame 1920x1200 batch, full detect + fitCylinderWPts3 solve, 1xMI355X"); with N > 1 every
+rank processes its own F frames (weak scaling, no data-path collective) and one RCCL all-gather of the
+128-byte pose records closes each step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+H, W = 1200, 1920
+BYTES_PER_FRAME = 2 * (H * W + 1024 * 24)          # 4 657 152 B per stereo frame
+HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/s HBM3E
+# algorithmic bytes per pixel of one launch (what the kernel must read + write once), DESIGN.md section 4
+ALGO_BYTES_PER_PX = {
+    'k_preprocess': 2.0,        # u8 frame in, u8 mask out
+    'k_ccl_init': 5.0,          # u8 image in, i32 label out
+    'k_ccl_merge': 5.0,         # u8 image in, i32 labels read (unions touch few of them)
+    'k_ccl_flatten': 8.0,       # i32 labels in, i32 labels out
+    'k_ccl_count': 5.0,         # i32 labels + u8 image in
+    'k_collect_roots': 4.0,     # i32 labels in
+    'k_morph_rect': 2.0,        # u8 in, u8 out
+    'k_blur_h': 3.0, 'k_blur_v': 3.0, 'k_clahe_apply': 2.0, 'k_and2': 3.0, 'k_and3': 4.0, 'k_or_and': 4.0,
+}
+
+
+def cpu_baseline(left, right, K1, K2, T21, radius, budget_s=20.0):
+    """the oracle (single-thread C restatement of the reference path) timed on this host: kind = "port" """
+    import oracle
+    from oracle import stages as S
+    oracle.build()
+    n = 0
+    t0 = time.time()
+    while n < left.shape[0]:
+        a = S.detect_grid(left[n]); b = S.detect_grid(right[n])
+        if a['status'] == 0 and b['status'] == 0:
+            gp1 = np.concatenate([a['xy'], a['id']], 1); gp2 = np.concatenate([b['xy'], b['id']], 1)
+            oracle.fit_single_cylinder(gp1, gp2, K1, K2, T21, radius)
+        n += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return dict(value=n / dt, unit='frames/s', cores=1, kind='port',
+                sample=f'{n} stereo frames {W}x{H} of the same synthetic workload, oracle detect_grid x2 + fitSingleCylinder, '
+                       f'one thread, {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--frames', type=int, default=4096, help='stereo frames per GPU per step')
+    ap.add_argument('--chunk', type=int, default=128, help='stereo frames per kernel batch (workspace size)')
+    ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes per GPU (cycled with fresh noise)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import cpe_amd
+    from cpe_amd import synth, pipeline, dist as D
+    rank, local, world = D.init_from_env('nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device(f'cuda:{local}')
+    torch.cuda.set_device(dev)
+    cpe_amd.lib.load()                                   # no CPU fallback: fail loudly
+
+    F = args.frames
+    # ---- synthetic inputs, resident in HBM: `unique` rendered scenes, every frame gets its own sensor noise
+    U = min(args.unique, F)
+    base = synth.render_batch(U, H, W, seed=1000 + rank, device=dev, with_gt=False)
+    K1, K2, T21, radius = base['K1'], base['K2'], base['T21'], base['radius']
+    left = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
+    right = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(7 + rank)
+    for i0 in range(0, F, U):
+        k = min(U, F - i0)
+        for src, dst in ((base['left'], left), (base['right'], right)):
+            if i0 == 0:
+                dst[:k] = src[:k]
+            else:   # same scenes, new noise realisation (+-1 DN on ~1/3 of the pixels)
+                nz = torch.randint(-1, 2, (k, H, W), generator=g, device=dev, dtype=torch.int16)
+                nz = nz * (torch.randint(0, 3, (k, H, W), generator=g, device=dev, dtype=torch.int16) == 0)
+                dst[i0:i0 + k] = (src[:k].to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
+    pipe = pipeline.FramePipeline(H, W, K1, K2, T21, radius, chunk=args.chunk, device=dev)
+
+    def step():
+        rec = pipe.run(left, right)
+        return D.gather_records(rec)
+
+    for _ in range(args.warmup):
+        allrec = step()
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allrec = step()
+    torch.cuda.synchronize(); D.barrier()
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, dev)
+
+    # ---- per-kernel hipEvent timers on one more (untimed) pass over one chunk: the dominant kernel's roofline
+    roof = None
+    if rank == 0:
+        cpe_amd.lib.profile(True)
+        c = min(args.chunk, F)
+        pipe.run_chunk(left[:c], right[:c])
+        torch.cuda.synchronize()
+        rep = cpe_amd.lib.profile_report()
+        cpe_amd.lib.profile(False)
+        tot = sum(r[2] for r in rep)
+        name, calls, ms = rep[0]
+        short = name.split('::')[-1]
+        px_per_launch = 2 * c * H * W
+        bpp = ALGO_BYTES_PER_PX.get(short)
+        if bpp is None:      # irregular kernel (border tracing ...): it has to see each frame's pixels at most once
+            bpp = 1.0
+        algo = bpp * px_per_launch
+        avg_s = ms / calls / 1e3
+        roof = dict(bound='hbm', kernel=short, calls_per_chunk=calls, avg_launch_ms=ms / calls, share_of_gpu_time=ms / tot,
+                    algorithmic_bytes_per_launch=algo, achieved=algo / avg_s / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                    frac=(algo / avg_s) / HBM_PEAK, traffic=None,
+                    top5=[dict(kernel=r[0].split('::')[-1], calls=r[1], ms=round(r[2], 3)) for r in rep[:5]])
+
+    if rank == 0:
+        n_pts, iters, fit_st, dl, dr = pipeline.unpack_counters(allrec[:, 15])
+        ok = ((fit_st == 0) & (dl == 0) & (dr == 0)).float().mean().item()
+        total_frames = F * world * args.steps
+        value = total_frames / dt
+        out = dict(metric='frames/sec (grid-detect + cylinder fit) on 1920x1200 batch', value=value, unit='frames/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+                   config=dict(workload=f'{F}-frame {W}x{H} stereo batch per GPU, full detect (both images) + chooseIdx + '
+                                        f'triangulate + fitCylinderWPts3 Nelder-Mead (BASELINE.json configs[2])',
+                               frames_per_gpu=F, chunk=args.chunk, unique_scenes=U,
+                               parallelism=f'frames sharded x{world}, all_gather of 128-B pose records'),
+                   frames_ok_fraction=ok, mean_points_per_frame=float(n_pts.float().mean().item()),
+                   path_hbm_frac=value * BYTES_PER_FRAME / HBM_PEAK / world,
+                   roofline=roof)
+        if not args.no_cpu_baseline:
+            m = min(12, F)
+            out['cpu_baseline'] = cpu_baseline(left[:m].cpu().numpy(), right[:m].cpu().numpy(), K1, K2, T21, radius)
+        print(json.dumps(out))
+    D.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -184,16 +184,16 @@ int ccl_label_count(const uint8_t *img, int n, int h, int w, int thr, int invert
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L, cnt);
-    hipLaunchKernelGGL(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
+    CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L, cnt);
+    CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
                        conn8, L);
-    hipLaunchKernelGGL(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);
+    CPE_KLAUNCH(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);
     if (touch) {
         (void)hipMemsetAsync(touch, 0, total, s);
         int per = 2 * w + 2 * h;
-        hipLaunchKernelGGL(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, L, n, h, w, touch);
+        CPE_KLAUNCH(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, L, n, h, w, touch);
     }
-    hipLaunchKernelGGL(k_ccl_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, L, total, h, w, thr, invert,
+    CPE_KLAUNCH(k_ccl_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, L, total, h, w, thr, invert,
                        interior_only, (const uint8_t *)touch, cnt);
     CPE_CHECK_LAUNCH("ccl_label_count");
     return CPE_OK;
@@ -204,10 +204,10 @@ int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int 
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L, (int *)nullptr);
-    hipLaunchKernelGGL(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
+    CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, L, (int *)nullptr);
+    CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, total, h, w, thr, invert,
                        conn8, L);
-    hipLaunchKernelGGL(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);
+    CPE_KLAUNCH(k_ccl_flatten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, L);
     CPE_CHECK_LAUNCH("ccl_label");
     return CPE_OK;
 }
@@ -218,13 +218,13 @@ int ccl_collect(const int *L, int n, int h, int w, bool holes_only, uint8_t *tou
 {
     const size_t N = (size_t)h * w, total = N * n;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_reset_roots, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    CPE_KLAUNCH(k_reset_roots, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
     if (holes_only && !touch_ready) {
         (void)hipMemsetAsync(touch, 0, total, s);
         int per = 2 * w + 2 * h;
-        hipLaunchKernelGGL(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, L, n, h, w, touch);
+        CPE_KLAUNCH(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, L, n, h, w, touch);
     }
-    hipLaunchKernelGGL(k_collect_roots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L,
+    CPE_KLAUNCH(k_collect_roots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L,
                        holes_only ? touch : (const uint8_t *)nullptr, total, N, roots, st);
     CPE_CHECK_LAUNCH("ccl_collect");
     return CPE_OK;

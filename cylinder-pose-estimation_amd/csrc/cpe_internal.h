@@ -51,6 +51,18 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
+// optional per-kernel hipEvent timers (cpe_profile_enable / cpe_profile_report); off by default, and a
+// no-op while off so the launch functions stay graph-capturable
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(hipStream_t s);
+
+#define CPE_KLAUNCH(kernel, grid, block, shmem, stream, ...)                         \
+    do {                                                                             \
+        cpe::prof_begin(#kernel, stream);                                            \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
+        cpe::prof_end(stream);                                                       \
+    } while (0)
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace cpe

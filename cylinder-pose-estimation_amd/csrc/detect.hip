@@ -143,7 +143,7 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
     int rc;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
     CPE_CHECK_LAUNCH("k_state_init");
     if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, stream)) != CPE_OK) return rc;
     if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
@@ -156,7 +156,7 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
                           n_pts, center, s)) != CPE_OK)
         return rc;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);
+    CPE_KLAUNCH(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);
     CPE_CHECK_LAUNCH("k_finish");
 #undef PL
     return CPE_OK;

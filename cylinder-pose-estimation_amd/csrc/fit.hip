@@ -808,7 +808,7 @@ extern "C" int32_t cpe_select_triangulate_batch(const double *xy1, const int32_t
         return CPE_ERR_WORKSPACE;
     }
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_select_triangulate, dim3(n), dim3(64), 0, (hipStream_t)stream, xy1, id1, cnt1, xy2, id2, cnt2,
+    CPE_KLAUNCH(k_select_triangulate, dim3(n), dim3(64), 0, (hipStream_t)stream, xy1, id1, cnt1, xy2, id2, cnt2,
                        K1, K2, T21, selector, patch, th, (int *)ws, p1, p2, idx, X, err, m, mean_err, flags);
     CPE_CHECK_LAUNCH("k_select_triangulate");
     return CPE_OK;
@@ -826,7 +826,7 @@ extern "C" int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, i
                   "cpe_fit_cylinder_batch: bad CpeFitParams");
     if (n == 0) return CPE_OK;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_fit_cylinder, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f,
+    CPE_KLAUNCH(k_fit_cylinder, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f,
                        p.max_iter, p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
     CPE_CHECK_LAUNCH("k_fit_cylinder");
     return CPE_OK;

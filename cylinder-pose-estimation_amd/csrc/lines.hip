@@ -408,7 +408,7 @@ int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, in
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, hipStream_t s)
 {
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
+    CPE_KLAUNCH(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
                        o_id, o_n, o_center);
     CPE_CHECK_LAUNCH("k_lines");
     return CPE_OK;

@@ -695,8 +695,8 @@ int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *
     const size_t total = (size_t)h * w * n;
     Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, src, total, h, w, t7, tmp16);
-    hipLaunchKernelGGL(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, tmp16, total, h, w, t7, dst);
+    CPE_KLAUNCH(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, src, total, h, w, t7, tmp16);
+    CPE_KLAUNCH(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, tmp16, total, h, w, t7, dst);
     CPE_CHECK_LAUNCH("blur7_u8");
     return CPE_OK;
 }
@@ -706,11 +706,11 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s)
 {
     const size_t total = (size_t)h * w * n;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 20, 1, 0, B.tmpA);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 20, 1, 1, B.hmask);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 1, 20, 0, B.tmpA);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 1, 20, 1, B.vmask);
-    hipLaunchKernelGGL(k_and2, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.vmask, total, B.joints_mask);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 20, 1, 0, B.tmpA);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 20, 1, 1, B.hmask);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 1, 20, 0, B.tmpA);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 1, 20, 1, B.vmask);
+    CPE_KLAUNCH(k_and2, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.vmask, total, B.joints_mask);
     CPE_CHECK_LAUNCH("joints_mask_stage");
     return CPE_OK;
 }
@@ -721,45 +721,45 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     const size_t total = (size_t)h * w * n;
     int rc;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
+    CPE_KLAUNCH(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
     // joints
     if ((rc = ccl_label(B.joints_mask, n, h, w, 0, 0, 1, B.lab, s)) != CPE_OK) return rc;
     if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
-    hipLaunchKernelGGL(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots, st, B.jtmp);
-    hipLaunchKernelGGL(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
+    CPE_KLAUNCH(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots, st, B.jtmp);
+    CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // spot
     Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
-    hipLaunchKernelGGL(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, gray, total, h, w, t19, B.tmp16);
-    hipLaunchKernelGGL(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, B.tmp16, total, h, w, t19, B.g19);
+    CPE_KLAUNCH(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, gray, total, h, w, t19, B.tmp16);
+    CPE_KLAUNCH(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, B.tmp16, total, h, w, t19, B.g19);
     if ((rc = ccl_label(B.g19, n, h, w, 240, 0, 1, B.lab, s)) != CPE_OK) return rc;
     if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
-    hipLaunchKernelGGL(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots, st, B.best);
+    CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots, st, B.best);
     (void)hipMemsetAsync(B.cm, 255, total, s);
-    hipLaunchKernelGGL(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best, st, B.verts, B.cm);
+    CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best, st, B.verts, B.cm);
     // roi masks: (mask & circle_mask & mask_contour) opened 3x3
-    hipLaunchKernelGGL(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.cm, B.mc, total, B.tmpA);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_h);
-    hipLaunchKernelGGL(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.vmask, B.cm, B.mc, total, B.tmpA);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
-    hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_v);
+    CPE_KLAUNCH(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.cm, B.mc, total, B.tmpA);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_h);
+    CPE_KLAUNCH(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.vmask, B.cm, B.mc, total, B.tmpA);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
+    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_v);
     CPE_CHECK_LAUNCH("masks_stage spot");
     // expansion
     for (int which = 0; which < 2; which++) {
         const uint8_t *roi = which ? B.roi_v : B.roi_h;
         uint8_t *base = which ? B.base_v : B.base_h;
         uint8_t *exp = which ? B.exp_v : B.exp_h;
-        hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, roi, total, h, w, 3, 3, 1, B.tmpA);
-        hipLaunchKernelGGL(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, base);
+        CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, roi, total, h, w, 3, 3, 1, B.tmpA);
+        CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, base);
         if ((rc = ccl_label(base, n, h, w, 0, 0, 1, B.lab, s)) != CPE_OK) return rc;
         if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
-        hipLaunchKernelGGL(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, base, h, w, which, B.roots, st,
+        CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, base, h, w, which, B.roots, st,
                            B.segs + (size_t)which * n * MAXSEG);
-        hipLaunchKernelGGL(k_seg_global, dim3(n), dim3(256), 0, s, st, which, B.segs + (size_t)which * n * MAXSEG);
+        CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, s, st, which, B.segs + (size_t)which * n * MAXSEG);
         (void)hipMemsetAsync(B.tmpB, 0, total, s);
-        hipLaunchKernelGGL(k_seg_expand, dim3(MAXSEG * 2, n), dim3(256), 0, s, base, h, w, which, st,
+        CPE_KLAUNCH(k_seg_expand, dim3(MAXSEG * 2, n), dim3(256), 0, s, base, h, w, which, st,
                            B.segs + (size_t)which * n * MAXSEG, B.tmpB);
-        hipLaunchKernelGGL(k_or_and, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, base, B.mc, total, exp);
+        CPE_KLAUNCH(k_or_and, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, base, B.mc, total, exp);
         CPE_CHECK_LAUNCH("masks_stage expand");
     }
     return CPE_OK;

@@ -242,7 +242,7 @@ extern "C" int32_t cpe_preprocess_batch(const uint8_t *gray, int32_t n, int32_t 
     long long blocks = (long long)n * tiles_x * tiles_y;
     CPE_CHECK_ARG(blocks < (1LL << 31), "cpe_preprocess_batch: grid too large");
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_preprocess, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gray, h, w,
+    CPE_KLAUNCH(k_preprocess, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gray, h, w,
                        tiles_x, tiles_y, mask);
     CPE_CHECK_LAUNCH("k_preprocess");
     return CPE_OK;

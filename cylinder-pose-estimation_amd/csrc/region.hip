@@ -489,37 +489,37 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if (clip > 0.0) { g.clipLimit = (int)(clip * tileTotal / 256); if (g.clipLimit < 1) g.clipLimit = 1; }
     g.lutScale = (float)255 / tileTotal;
     CPE_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
+    CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
     (void)hipMemsetAsync(B.hist, 0, (size_t)n * 16 * 256 * sizeof(unsigned int), s);
     const int strips = 8;
-    hipLaunchKernelGGL(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
-    hipLaunchKernelGGL(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
+    CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist);
+    CPE_KLAUNCH(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
+    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
     CPE_CHECK_LAUNCH("clahe");
     for (int thr = 50; thr < 220; thr += 10) {
         int rc;
         // bright components: outer borders
         if ((rc = ccl_label_count(B.cl, n, h, w, thr, 0, 1, B.lab, B.cnt, 1, nullptr, s)) != CPE_OK) return rc;
         if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
-        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
+        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
                            B.blob_d, B.dists);
         // enclosed dark components: hole borders
         if ((rc = ccl_label_count(B.cl, n, h, w, thr, 1, 0, B.lab, B.cnt, 0, B.touch, s)) != CPE_OK) return rc;
         if ((rc = ccl_collect(B.lab, n, h, w, true, B.touch, B.roots, st, s, true)) != CPE_OK) return rc;
-        hipLaunchKernelGGL(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
+        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
                            B.blob_d, B.dists);
-        hipLaunchKernelGGL(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
-        hipLaunchKernelGGL(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
+        CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
+        CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
         CPE_CHECK_LAUNCH("blob threshold pass");
     }
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
-    hipLaunchKernelGGL(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
+    CPE_KLAUNCH(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
     int rc;
     if ((rc = ccl_label(B.ext, n, h, w, 0, 0, 1, B.lab, s)) != CPE_OK) return rc;
     if ((rc = ccl_collect(B.lab, n, h, w, false, nullptr, B.roots, st, s)) != CPE_OK) return rc;
-    hipLaunchKernelGGL(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.ext, h, w, B.roots, st, B.best);
-    hipLaunchKernelGGL(k_hull_fill, dim3(n), dim3(256), 0, s, B.ext, h, w, B.best, st, B.lohi, B.hull, B.mc);
+    CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.ext, h, w, B.roots, st, B.best);
+    CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, B.ext, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
     return CPE_OK;
 }

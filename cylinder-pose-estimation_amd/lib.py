@@ -26,6 +26,8 @@ def build(verbose=False):
 _SIGS = {
     'cpe_version': (C.c_int32, []),
     'cpe_last_error_string': (C.c_char_p, []),
+    'cpe_profile_enable': (None, [C.c_int32]),
+    'cpe_profile_report': (C.c_int32, [C.c_char_p, C.c_size_t]),
     'cpe_preprocess_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_detect_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'cpe_detect_grid_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t] +
@@ -65,6 +67,21 @@ def check(rc, what):
     if rc != 0:
         msg = load().cpe_last_error_string().decode()
         raise CpeError(f'{what} failed (rc={rc}): {msg}')
+
+
+def profile(on):
+    load().cpe_profile_enable(1 if on else 0)
+
+
+def profile_report():
+    """-> list of (kernel, calls, total_ms) sorted by total time (descending); clears the timers"""
+    buf = C.create_string_buffer(1 << 16)
+    load().cpe_profile_report(buf, len(buf))
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.rsplit(',', 2)
+        out.append((name, int(calls), float(ms)))
+    return out
 
 
 def declared_symbols():

@@ -1,0 +1,66 @@
+"""Whole hot path for a batch of stereo frames, resident on one GPU:
+    left/right u8 [F,h,w]  ->  detect_grid (both images)  ->  fitSingleCylinder  ->  pose records [F,16] f64
+
+This is the loop body of exp_gridDetection.m:55-81 (makePyGridPts L/R, then fitSingleCylinder per frame)
+turned into batched kernel launches; frames are processed in chunks so that the detect workspace stays
+bounded (about 75 MB per 1920x1200 image)."""
+import torch
+
+from . import api, fit
+
+REC = 16   # f64 per frame: cyl0[6] | cyl[6] (both after applyCylParamsPrior) | f0 f | meanError | packed counters
+
+
+def pack_counters(n_pts, iters, fit_status, det_l, det_r):
+    """n_pts (<2048), iterations (<2^20), statuses -> one exactly representable double"""
+    code = n_pts.to(torch.int64) + 2048 * (iters.to(torch.int64) + (1 << 20) * (fit_status.to(torch.int64) * 64 +
+                                                                                 det_l.to(torch.int64) * 8 + det_r.to(torch.int64)))
+    return code.to(torch.float64)
+
+
+def unpack_counters(code):
+    code = code.to(torch.int64)
+    n_pts = code % 2048
+    rest = code // 2048
+    iters = rest % (1 << 20)
+    st = rest // (1 << 20)
+    return n_pts, iters, st // 64, (st // 8) % 8, st % 8
+
+
+class FramePipeline:
+    """reusable workspaces for chunks of `chunk` stereo frames of size h x w"""
+
+    def __init__(self, h, w, K1, K2, T21, radius, chunk=64, device='cuda:0', selector=fit.SEL_CHOOSE_IDX, th=0.3):
+        self.h, self.w, self.chunk, self.device = h, w, chunk, torch.device(device)
+        self.K1, self.K2, self.T21, self.radius = K1, K2, T21, radius
+        self.selector, self.th = selector, th
+        self.ws = {}
+
+    def _ws(self, n_img):
+        if n_img not in self.ws:
+            self.ws[n_img] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
+        return self.ws[n_img]
+
+    def run_chunk(self, left, right):
+        c = left.shape[0]
+        frames = torch.cat([left, right])                 # [2c,h,w]: one detect call for both cameras
+        det = api.detect_grid_batch(frames, self._ws(2 * c))
+        g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
+        g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
+        out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th)
+        rec = torch.empty((c, REC), dtype=torch.float64, device=frames.device)
+        rec[:, 0:6] = out['cyl'][:, 0]
+        rec[:, 6:12] = out['cyl'][:, 1]
+        rec[:, 12:14] = out['fvals']
+        rec[:, 14] = out['mean_err']
+        rec[:, 15] = pack_counters(out['m'], out['iters'][:, 0], out['status'], det['status'][:c], det['status'][c:])
+        return rec, det, out
+
+    def run(self, left, right):
+        """left/right: u8 [F,h,w] on the device -> records f64 [F,16]"""
+        F = left.shape[0]
+        recs = torch.empty((F, REC), dtype=torch.float64, device=left.device)
+        for i0 in range(0, F, self.chunk):
+            i1 = min(F, i0 + self.chunk)
+            recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1])[0]
+        return recs

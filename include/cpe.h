@@ -56,6 +56,13 @@ extern "C" {
 CPE_API int32_t cpe_version(void);
 CPE_API const char *cpe_last_error_string(void);
 
+/* Per-kernel hipEvent timers (the build's stand-in for the reference's commented line_profiler hooks,
+ * util_cylinder.py:2010-2011).  Off by default; while on, every internal launch is bracketed by events on
+ * its stream.  cpe_profile_report synchronises them, writes "kernel,calls,total_ms" lines (descending)
+ * into csv and clears the records; returns the number of distinct kernels. */
+CPE_API void cpe_profile_enable(int32_t on);
+CPE_API int32_t cpe_profile_report(char *csv, size_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * Stage a-1: load_and_preprocess_image (util_cylinder.py:1769-1802) for a batch of frames.
  *   gray  u8[n,h,w]  ->  mask u8[n,h,w]  (255 = ridge: Hessian(sigma 3) smaller eigenvalue <= Sauvola

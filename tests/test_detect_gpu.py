@@ -109,3 +109,33 @@ def test_reference_signature_and_json(cpe, orc, gpu):
     bgr = np.repeat(f[0][..., None], 3, axis=2)                                       # cv2.imread-style grey BGR
     assert cpe.api.detect_grid(bgr)[1] == result_json
     assert cpe.api.detect_grid(np.full((480, 640), 5, np.uint8)) is None              # reference: prints + None
+
+
+@pytest.mark.gpu
+def test_pipeline_records_and_profile(cpe, orc, gpu):
+    """FramePipeline end to end vs oracle (records), chunking invariance, and the per-kernel timers"""
+    from oracle import stages as S
+    from cpe_amd import synth, pipeline
+    b = synth.render_batch(3, 480, 640, seed=5, with_gt=False)
+    L, R = b['left'].to(gpu), b['right'].to(gpu)
+    p1 = pipeline.FramePipeline(480, 640, b['K1'], b['K2'], b['T21'], 45.0, chunk=3, device=gpu)
+    p2 = pipeline.FramePipeline(480, 640, b['K1'], b['K2'], b['T21'], 45.0, chunk=2, device=gpu)
+    cpe.lib.profile(True)
+    r1 = p1.run(L, R)
+    torch.cuda.synchronize()
+    rep = cpe.lib.profile_report()
+    cpe.lib.profile(False)
+    assert any('k_preprocess' in r[0] for r in rep) and any('k_fit_cylinder' in r[0] for r in rep)
+    assert all(r[2] >= 0 for r in rep)
+    r2 = p2.run(L, R)
+    assert torch.equal(r1, r2)                                      # ragged last chunk, same results
+    n_pts, iters, fs, dl, dr = pipeline.unpack_counters(r1[:, 15])
+    for i in range(3):
+        a, c = S.detect_grid(b['left'][i].numpy()), S.detect_grid(b['right'][i].numpy())
+        assert (int(dl[i]), int(dr[i])) == (a['status'], c['status'])
+        if a['status'] == 0 and c['status'] == 0:
+            ref = orc.fit_single_cylinder(np.concatenate([a['xy'], a['id']], 1), np.concatenate([c['xy'], c['id']], 1),
+                                          b['K1'], b['K2'], b['T21'], 45.0)
+            assert np.array_equal(r1[i, :12].cpu().numpy(), ref['cyl'].ravel())
+            assert np.array_equal(r1[i, 12:14].cpu().numpy(), ref['fvals'])
+            assert int(n_pts[i]) == len(ref['pts3']) and int(iters[i]) == ref['iters']
