@@ -51,6 +51,8 @@ struct FrameState {
     int n_rows, n_cols;
     int overflow;
     int hull_n;
+    int crect[4];       // working rectangle of a restricted labelling pass (x0, y0, x1, y1)
+    int nrect[4];       // bounding-box accumulator
     int pad[3];
 };
 

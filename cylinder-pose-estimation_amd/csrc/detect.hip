@@ -11,7 +11,9 @@
 
 namespace cpe {
 
-int ccl_label(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, hipStream_t s);
+int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int want_bbox, FrameState *st, hipStream_t s);
+int ccl_ctl(FrameState *st, int n, int h, int w, int op, hipStream_t s);
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
@@ -149,8 +151,8 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
     if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
     if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_label(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), s)) != CPE_OK) return rc;
-    if ((rc = ccl_label(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 0, 0, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, 0, st, s)) != CPE_OK) return rc;
     if ((rc = blur7_u8(gray, n, h, w, M.tmp16, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
     if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                           n_pts, center, s)) != CPE_OK)
