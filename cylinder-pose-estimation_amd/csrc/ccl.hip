@@ -167,8 +167,12 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
                 mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
             }
             if (lane == leader) {
-                atomicMin(&st[lf].nrect[0], mnx); atomicMin(&st[lf].nrect[1], mny);
-                atomicMax(&st[lf].nrect[2], mxx); atomicMax(&st[lf].nrect[3], mxy);
+                // most wavefronts already lie inside the accumulated box: test first, keep the atomics rare
+                int *nr = st[lf].nrect;
+                if (mnx < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, mnx);
+                if (mny < __hip_atomic_load(nr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 1, mny);
+                if (mxx > __hip_atomic_load(nr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 2, mxx);
+                if (mxy > __hip_atomic_load(nr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 3, mxy);
             }
             act &= ~__ballot(mine);
         }
