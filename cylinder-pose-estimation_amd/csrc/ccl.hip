@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             int leader = __ffsll((long long)active) - 1;
             long long lk = __shfl(key, leader, 64);
             unsigned long long same = __ballot(key == lk) & active;
-            if (lane == leader) atomicAdd(&cnt[lk], __popcll(same));
+            // only "count >= 5000" is ever asked: once a component is past that, stop hammering its counter
+            if (lane == leader && __hip_atomic_load(&cnt[lk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 5000)
+                atomicAdd(&cnt[lk], __popcll(same));
             active &= ~same;
         }
     }
