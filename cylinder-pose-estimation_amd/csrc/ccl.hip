@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
         if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) {
             int v = L[gi];
             if (v >= 0) {
-                root = uf_find(L + f * N, v);
+                root = uf_find_c(L + f * N, v);
                 L[gi] = root;
             }
         }
@@ -201,9 +201,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             int leader = __ffsll((long long)active) - 1;
             long long lk = __shfl(key, leader, 64);
             unsigned long long same = __ballot(key == lk) & active;
-            // only "count >= 5000" is ever asked: once a component is past that, stop hammering its counter
-            if (lane == leader && __hip_atomic_load(&cnt[lk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 5000)
-                atomicAdd(&cnt[lk], __popcll(same));
+            if (lane == leader) atomicAdd(&cnt[lk], __popcll(same));
             active &= ~same;
         }
     }

@@ -91,11 +91,27 @@ __device__ __forceinline__ int uf_find(const int *L, int x)
     while ((p = uf_load(L, x)) != x) x = p;
     return x;
 }
+// find with intermediate pointer jumping (ECL-CC): every node on the walked path is re-pointed at its
+// grandparent.  Parents always have smaller indices and roots are never written, so concurrent use with
+// uf_unite is safe; stale writes can only re-point a node at another of its ancestors.
+__device__ __forceinline__ int uf_find_c(int *L, int x)
+{
+    int curr = uf_load(L, x);
+    if (curr != x) {
+        int prev = x, next;
+        while (curr > (next = uf_load(L, curr))) {
+            __hip_atomic_store(L + prev, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = curr;
+            curr = next;
+        }
+    }
+    return curr;
+}
 __device__ __forceinline__ void uf_unite(int *L, int a, int b)
 {
     for (;;) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = uf_find_c(L, a);
+        b = uf_find_c(L, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(&L[a], b);
