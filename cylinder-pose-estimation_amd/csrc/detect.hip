@@ -104,9 +104,10 @@ extern "C" size_t cpe_detect_workspace_bytes(int32_t n, int32_t h, int32_t w)
 extern "C" int32_t cpe_detect_workspace_plane(int32_t n, int32_t h, int32_t w, int32_t plane, size_t *offset,
                                               size_t *bytes_per_frame)
 {
-    CPE_CHECK_ARG(n > 0 && h > 0 && w > 0 && plane >= 0 && plane <= P_G7 && offset && bytes_per_frame,
+    CPE_CHECK_ARG(n > 0 && h > 0 && w > 0 && plane >= 0 && plane <= P_G7 + 1 && offset && bytes_per_frame,
                   "cpe_detect_workspace_plane: bad argument");
     Layout L = make_layout(n, h, w);
+    if (plane == P_G7 + 1) plane = P_LAB0;
     *offset = L.off[plane];
     *bytes_per_frame = L.bytes_per_frame[plane];
     return CPE_OK;
@@ -162,4 +163,20 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     CPE_CHECK_LAUNCH("k_finish");
 #undef PL
     return CPE_OK;
+}
+
+// Stand-alone labelling pass over the workspace's label planes (profiling / tests): labels of
+// {(img > thr) != invert} land in the CPE_PLANE_LABELS plane.
+extern "C" int32_t cpe_debug_ccl(const uint8_t *img, int32_t n, int32_t h, int32_t w, int32_t thr, int32_t invert,
+                                 int32_t conn8, int32_t count_mode, int32_t want_bbox, int32_t want_roots, void *ws,
+                                 size_t ws_bytes, void *stream)
+{
+    CPE_CHECK_ARG(img && ws && n > 0 && h >= 64 && w >= 64, "cpe_debug_ccl: bad argument");
+    Layout L = make_layout(n, h, w);
+    CPE_CHECK_ARG(ws_bytes >= L.total && ((uintptr_t)ws & 255) == 0, "cpe_debug_ccl: workspace too small or misaligned");
+    uint8_t *base = (uint8_t *)ws;
+    hipStream_t s = (hipStream_t)stream;
+    FrameState *st = (FrameState *)(base + L.off[P_STATE]);
+    return ccl_run(img, n, h, w, thr, invert, conn8, (int *)(base + L.off[P_LAB0]), want_roots ? (int *)(base + L.off[P_ROOTS]) : nullptr,
+                   invert != 0, (uint8_t *)(base + L.off[P_TOUCH]), count_mode, (int *)(base + L.off[P_LAB1]), 0, want_bbox, st, s);
 }

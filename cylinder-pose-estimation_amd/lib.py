@@ -33,6 +33,7 @@ _SIGS = {
     'cpe_detect_grid_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t] +
                               [C.c_void_p] * 6),
     'cpe_detect_workspace_plane': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'cpe_debug_ccl': (C.c_int32, [C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     'cpe_fit_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'cpe_select_triangulate_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 +
                                      [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),

@@ -107,6 +107,15 @@ CPE_API int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t h,
 CPE_API int32_t cpe_detect_workspace_plane(int32_t n, int32_t h, int32_t w, int32_t plane, size_t *offset,
                                            size_t *bytes_per_frame);
 
+/* One stand-alone connected-component pass (cv2.connectedComponents / the front end of cv2.findContours,
+ * util_cylinder.py:28,161,1817,1883,1968) over img u8[n,h,w]: set = (img > thr) != invert, 8- or 4-connected;
+ * labels (raster index of the component's first pixel, -1 outside the set) land in workspace plane
+ * CPE_PLANE_LABELS.  count_mode / want_bbox / want_roots switch the optional by-products (profiling aid). */
+#define CPE_PLANE_LABELS 13       /* i32[h,w] */
+CPE_API int32_t cpe_debug_ccl(const uint8_t *img, int32_t n, int32_t h, int32_t w, int32_t thr, int32_t invert,
+                              int32_t conn8, int32_t count_mode, int32_t want_bbox, int32_t want_roots, void *ws,
+                              size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grid-point tables.  One table per image: xy f64[n,CPE_MAXP,2] pixel coordinates, id i32[n,CPE_MAXP,2]
  * (col,row) grid indices, cnt i32[n] -- the padded form of the reference's N x 4 matrix

@@ -1,0 +1,21 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, cpe_amd
+from cpe_amd import synth, api
+n = 64
+b = synth.render_batch(n // 2, 1200, 1920, seed=1, device='cuda', with_gt=False)
+frames = torch.cat([b['left'], b['right']])
+ws = api.DetectWorkspace(n, 1200, 1920, frames.device)
+det = api.detect_grid_batch(frames, ws)
+cl = ws.plane('clahe').clone()
+L = cpe_amd.lib.load()
+def run(thr, inv, conn8, cm, bbox, roots):
+    cpe_amd.lib.check(L.cpe_debug_ccl(cl.data_ptr(), n, 1200, 1920, thr, inv, conn8, cm, bbox, roots, ws.view.data_ptr(), ws.bytes, torch.cuda.current_stream().cuda_stream), 'ccl')
+for (thr, inv, conn8) in ((100, 0, 1), (100, 1, 0)):
+    for cm, bbox, roots in ((0,0,0),(0,0,1),(2 if not inv else 1,0,0),(0,1,0),(2 if not inv else 1,1,1)):
+        run(thr, inv, conn8, cm, bbox, roots); torch.cuda.synchronize()
+        cpe_amd.lib.profile(True)
+        for _ in range(3): run(thr, inv, conn8, cm, bbox, roots)
+        torch.cuda.synchronize()
+        rep = cpe_amd.lib.profile_report(); cpe_amd.lib.profile(False)
+        print(f'thr {thr} inv {inv} count {cm} bbox {bbox} roots {roots}: ' + ' '.join(f"{r[0].split('::')[-1][6:]}={r[2]/r[1]:.2f}ms" for r in rep))
