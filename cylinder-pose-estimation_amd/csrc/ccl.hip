@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, in
 __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ img, size_t total, int h, int w, int thr,
                                                     int invert, FrameState *__restrict__ st, int use_rect,
                                                     int *__restrict__ L, const uint8_t *__restrict__ touch, int count_mode,
-                                                    int *__restrict__ cnt, int *__restrict__ roots, int want_bbox)
+                                                    int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect)
 {
     size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t N = (size_t)h * w;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
         }
     }
     const bool in = root >= 0;
-    if (want_bbox) {
+    if (nrect) {
         // the lanes of one wavefront lie in one frame except at frame boundaries: reduce per leader frame
         unsigned long long act = __ballot(in);
         while (act) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             }
             if (lane == leader) {
                 // most wavefronts already lie inside the accumulated box: test first, keep the atomics rare
-                int *nr = st[lf].nrect;
+                int *nr = nrect + 16 * lf;   // 64 B apart: one cache line per frame, away from the rectangles being read
                 if (mnx < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, mnx);
                 if (mny < __hip_atomic_load(nr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 1, mny);
                 if (mxx > __hip_atomic_load(nr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 2, mxx);
@@ -207,44 +207,45 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
     }
 }
 
-__global__ void k_ccl_ctl(FrameState *st, int n, int h, int w, int op)
+__global__ void k_ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     FrameState &S = st[f];
+    int *nr = nrect ? nrect + 16 * f : nullptr;
     if (op == 0) {          // reset the root list
         S.n_roots = 0;
     } else if (op == 1) {   // working rectangle = whole frame, accumulator empty
         S.crect[0] = 0; S.crect[1] = 0; S.crect[2] = w - 1; S.crect[3] = h - 1;
-        S.nrect[0] = INT_MAX; S.nrect[1] = INT_MAX; S.nrect[2] = -1; S.nrect[3] = -1;
+        nr[0] = INT_MAX; nr[1] = INT_MAX; nr[2] = -1; nr[3] = -1;
     } else if (op == 2) {   // working rectangle = accumulated bounding box; accumulator emptied
-        for (int k = 0; k < 4; k++) S.crect[k] = S.nrect[k];
-        S.nrect[0] = INT_MAX; S.nrect[1] = INT_MAX; S.nrect[2] = -1; S.nrect[3] = -1;
+        for (int k = 0; k < 4; k++) { S.crect[k] = nr[k]; S.nrect[k] = nr[k]; }
+        nr[0] = INT_MAX; nr[1] = INT_MAX; nr[2] = -1; nr[3] = -1;
     }
     // op 3: keep crect (a superset of the next, smaller set), accumulator already empty
 }
 
 }  // namespace
 
-int ccl_ctl(FrameState *st, int n, int h, int w, int op, hipStream_t s)
+int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s)
 {
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, n, h, w, op);
+    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, op);
     CPE_CHECK_LAUNCH("k_ccl_ctl");
     return CPE_OK;
 }
 
 // One labelling pass.  roots (optional): component list in st[].n_roots / roots; holes_only drops components
 // that reach the border of the working rectangle (needs `touch`); count_mode/cnt as in k_ccl_finish;
-// use_rect: restrict to st[].crect; want_bbox: accumulate the set's bounding box into st[].nrect.
+// use_rect: restrict to st[].crect; nrect (optional, int[n][16]): accumulate the set's bounding box there.
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int want_bbox, FrameState *st, hipStream_t s)
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s)
 {
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
     const unsigned gpx = (unsigned)((total + 255) / 256);
     CPE_LAUNCH_BEGIN();
-    if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, n, h, w, 0);
+    if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0);
     CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                 count_mode ? cnt : (int *)nullptr);
     CPE_KLAUNCH(k_ccl_merge, dim3(gpx), dim3(256), 0, s, img, total, h, w, thr, invert, conn8, (const FrameState *)st, use_rect, L);
@@ -255,7 +256,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
                     use_rect, touch);
     }
     CPE_KLAUNCH(k_ccl_finish, dim3(gpx), dim3(256), 0, s, img, total, h, w, thr, invert, st, use_rect, L,
-                holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, want_bbox);
+                holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;
 }

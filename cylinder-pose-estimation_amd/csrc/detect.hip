@@ -12,8 +12,8 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int want_bbox, FrameState *st, hipStream_t s);
-int ccl_ctl(FrameState *st, int n, int h, int w, int op, hipStream_t s);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s);
+int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
@@ -25,16 +25,18 @@ int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, in
 namespace {
 
 struct Layout {
-    size_t off[40];
-    size_t bytes_per_frame[40];
+    size_t off[48];
+    size_t bytes_per_frame[48];
     size_t total;
 };
 
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_COUNT
 };
+
+static_assert(P_COUNT <= 48, "Layout arrays too small");
 
 Layout make_layout(int n, int h, int w)
 {
@@ -62,6 +64,7 @@ Layout make_layout(int n, int h, int w)
     per[P_LOHI] = (size_t)2 * w * sizeof(int);
     per[P_HULL] = (size_t)4 * w * sizeof(int);
     per[P_LINES] = lines_ws_bytes();
+    per[P_NRECT] = 16 * sizeof(int);
     size_t o = 0;
     for (int i = 0; i < P_COUNT; i++) {
         L.off[i] = o;
@@ -133,7 +136,7 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     FrameState *st = PL(FrameState, P_STATE);
     RegionBuffers R;
     R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
-    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
+    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
     R.blobs = PL(BlobRec, P_BLOBS); R.blob_d = PL(int, P_BLOB_D); R.order = PL(int, P_ORDER); R.dists = PL(double, P_DISTS);
     R.groups = PL(Group, P_GROUPS); R.best = PL(unsigned long long, P_BEST); R.lohi = PL(int, P_LOHI); R.hull = PL(int, P_HULL);
     MaskBuffers M;
@@ -152,8 +155,8 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
     if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
     if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 0, 0, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, 0, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
     if ((rc = blur7_u8(gray, n, h, w, M.tmp16, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
     if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                           n_pts, center, s)) != CPE_OK)
@@ -178,5 +181,6 @@ extern "C" int32_t cpe_debug_ccl(const uint8_t *img, int32_t n, int32_t h, int32
     hipStream_t s = (hipStream_t)stream;
     FrameState *st = (FrameState *)(base + L.off[P_STATE]);
     return ccl_run(img, n, h, w, thr, invert, conn8, (int *)(base + L.off[P_LAB0]), want_roots ? (int *)(base + L.off[P_ROOTS]) : nullptr,
-                   invert != 0, (uint8_t *)(base + L.off[P_TOUCH]), count_mode, (int *)(base + L.off[P_LAB1]), 0, want_bbox, st, s);
+                   invert != 0, (uint8_t *)(base + L.off[P_TOUCH]), count_mode, (int *)(base + L.off[P_LAB1]), 0,
+                   want_bbox ? (int *)(base + L.off[P_NRECT]) : nullptr, st, s);
 }

@@ -15,8 +15,8 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int want_bbox, FrameState *st, hipStream_t s);
-int ccl_ctl(FrameState *st, int n, int h, int w, int op, hipStream_t s);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s);
+int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 
 namespace {
 
@@ -495,27 +495,25 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
-    if ((rc = ccl_ctl(st, n, h, w, 1, s)) != CPE_OK) return rc;          // working rectangle = whole frame
+    if ((rc = ccl_ctl(st, B.nrect, n, h, w, 1, s)) != CPE_OK) return rc;          // working rectangle = whole frame
     for (int thr = 50; thr < 220; thr += 10) {
         // bright components (8-conn) inside the previous threshold's box: outer borders; accumulates this box
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 2, B.cnt, 1, 1, st, s)) != CPE_OK) return rc;
+        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 2, B.cnt, 1, B.nrect, st, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
                     B.blob_d, B.dists);
-        if ((rc = ccl_ctl(st, n, h, w, 2, s)) != CPE_OK) return rc;      // working rectangle = box of the bright pixels
+        if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;      // working rectangle = box of the bright pixels
         // enclosed dark components (4-conn): hole borders
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, true, B.touch, 1, B.cnt, 1, 0, st, s)) != CPE_OK) return rc;
+        if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, true, B.touch, 1, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
                     B.blob_d, B.dists);
         CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
         CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
         CPE_CHECK_LAUNCH("blob threshold pass");
-        // the next threshold's bright pixels are a subset of this one's: keep crect, its box accumulates afresh
-        if ((rc = ccl_ctl(st, n, h, w, 3, s)) != CPE_OK) return rc;
     }
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
     CPE_KLAUNCH(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
-    if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, 0, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.ext, h, w, B.roots, st, B.best);
     CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, B.ext, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
