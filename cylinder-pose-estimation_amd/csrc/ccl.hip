@@ -130,19 +130,20 @@ __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, in
 //   the image).  Exact prune bounds of the blob detector: a hole of >= 5000 pixels, or a bright component with
 //   >= 5000 interior pixels, has border-polygon area >= 5000 (polygon edges only cross the unit squares of their
 //   own end-point pixels).
-__global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ img, size_t total, int h, int w, int thr,
+__global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                     int invert, FrameState *__restrict__ st, int use_rect,
                                                     int *__restrict__ L, const uint8_t *__restrict__ touch, int count_mode,
                                                     int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect)
 {
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid = (ceil(N / 256), n): a workgroup never straddles two frames, so every wave-level aggregate below is
+    // per frame
     const size_t N = (size_t)h * w;
+    const size_t f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    size_t f = 0;
-    int root = -1, x = 0, y = 0, i = 0;
-    if (gi < total) {
-        f = gi / N;
-        i = (int)(gi - f * N);
+    const size_t gi = f * N + (size_t)i;
+    int root = -1, x = 0, y = 0;
+    if ((size_t)i < N) {
         y = i / w; x = i - y * w;
         const Rect r = get_rect(st, f, use_rect, h, w);
         if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) {
@@ -154,34 +155,37 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
         }
     }
     const bool in = root >= 0;
-    if (nrect) {
-        // the lanes of one wavefront lie in one frame except at frame boundaries: reduce per leader frame
-        unsigned long long act = __ballot(in);
-        while (act) {
-            int leader = __ffsll((long long)act) - 1;
-            size_t lf = (size_t)__shfl((long long)f, leader, 64);
-            bool mine = in && f == lf;
-            int mnx = mine ? x : INT_MAX, mxx = mine ? x : INT_MIN, mny = mine ? y : INT_MAX, mxy = mine ? y : INT_MIN;
-            for (int off = 32; off >= 1; off >>= 1) {
-                mnx = min(mnx, __shfl_xor(mnx, off, 64)); mxx = max(mxx, __shfl_xor(mxx, off, 64));
-                mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
-            }
-            if (lane == leader) {
-                // most wavefronts already lie inside the accumulated box: test first, keep the atomics rare
-                int *nr = nrect + 16 * lf;   // 64 B apart: one cache line per frame, away from the rectangles being read
-                if (mnx < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, mnx);
-                if (mny < __hip_atomic_load(nr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 1, mny);
-                if (mxx > __hip_atomic_load(nr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 2, mxx);
-                if (mxy > __hip_atomic_load(nr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 3, mxy);
-            }
-            act &= ~__ballot(mine);
+    if (nrect && __ballot(in)) {
+        int mnx = in ? x : INT_MAX, mxx = in ? x : INT_MIN, mny = in ? y : INT_MAX, mxy = in ? y : INT_MIN;
+        for (int off = 32; off >= 1; off >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, off, 64)); mxx = max(mxx, __shfl_xor(mxx, off, 64));
+            mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
+        }
+        if (lane == 0) {
+            // most wavefronts already lie inside the accumulated box: test first, keep the atomics rare
+            int *nr = nrect + 16 * f;   // 64 B per frame: its own cache line
+            if (mnx < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, mnx);
+            if (mny < __hip_atomic_load(nr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 1, mny);
+            if (mxx > __hip_atomic_load(nr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 2, mxx);
+            if (mxy > __hip_atomic_load(nr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 3, mxy);
         }
     }
     const bool touched = in && touch && touch[f * N + root];
-    if (in && !touched && root == i && roots) {
-        int k = atomicAdd(&st[f].n_roots, 1);
-        if (k < MAXROOTS) roots[f * MAXROOTS + k] = i;
-        else st[f].overflow = 1;
+    if (roots) {
+        // root list: one atomic per wavefront
+        const bool is_root = in && !touched && root == i;
+        unsigned long long rb = __ballot(is_root);
+        if (rb) {
+            int base = 0;
+            const int leader = __ffsll((long long)rb) - 1;
+            if (lane == leader) base = atomicAdd(&st[f].n_roots, __popcll(rb));
+            base = __shfl(base, leader, 64);
+            if (is_root) {
+                int k = base + __popcll(rb & ((1ull << lane) - 1ull));
+                if (k < MAXROOTS) roots[f * MAXROOTS + k] = i;
+                else st[f].overflow = 1;
+            }
+        }
     }
     if (count_mode) {
         bool c = in && !touched;
@@ -195,13 +199,13 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             }
             c = inter;
         }
-        long long key = c ? (long long)(f * N) + root : -1;
+        int key = c ? root : -1;
         unsigned long long active = __ballot(key >= 0);
         while (active) {
             int leader = __ffsll((long long)active) - 1;
-            long long lk = __shfl(key, leader, 64);
+            int lk = __shfl(key, leader, 64);
             unsigned long long same = __ballot(key == lk) & active;
-            if (lane == leader) atomicAdd(&cnt[lk], __popcll(same));
+            if (lane == leader) atomicAdd(&cnt[f * N + lk], __popcll(same));
             active &= ~same;
         }
     }
@@ -255,7 +259,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
         CPE_KLAUNCH(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const int *)L, n, h, w, (const FrameState *)st,
                     use_rect, touch);
     }
-    CPE_KLAUNCH(k_ccl_finish, dim3(gpx), dim3(256), 0, s, img, total, h, w, thr, invert, st, use_rect, L,
+    CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
                 holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;
