@@ -181,6 +181,6 @@ extern "C" int32_t cpe_debug_ccl(const uint8_t *img, int32_t n, int32_t h, int32
     hipStream_t s = (hipStream_t)stream;
     FrameState *st = (FrameState *)(base + L.off[P_STATE]);
     return ccl_run(img, n, h, w, thr, invert, conn8, (int *)(base + L.off[P_LAB0]), want_roots ? (int *)(base + L.off[P_ROOTS]) : nullptr,
-                   invert != 0, (uint8_t *)(base + L.off[P_TOUCH]), count_mode, (int *)(base + L.off[P_LAB1]), 0,
-                   want_bbox ? (int *)(base + L.off[P_NRECT]) : nullptr, st, s);
+                   invert != 0, (uint8_t *)(base + L.off[P_TOUCH]), count_mode, (int *)(base + L.off[P_LAB1]), (want_bbox >> 1) & 1,
+                   (want_bbox & 1) ? (int *)(base + L.off[P_NRECT]) : nullptr, st, s);
 }

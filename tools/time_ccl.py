@@ -11,11 +11,13 @@ cl = ws.plane('clahe').clone()
 L = cpe_amd.lib.load()
 def run(thr, inv, conn8, cm, bbox, roots):
     cpe_amd.lib.check(L.cpe_debug_ccl(cl.data_ptr(), n, 1200, 1920, thr, inv, conn8, cm, bbox, roots, ws.view.data_ptr(), ws.bytes, torch.cuda.current_stream().cuda_stream), 'ccl')
-for (thr, inv, conn8) in ((100, 0, 1), (100, 1, 0)):
-    for cm, bbox, roots in ((0,0,0),(0,0,1),(2 if not inv else 1,0,0),(0,1,0),(2 if not inv else 1,1,1)):
-        run(thr, inv, conn8, cm, bbox, roots); torch.cuda.synchronize()
+print(ws.state()[0])
+for thr in (50, 60, 100, 200):
+    for cm, bbox, roots in ((0,0,0),(0,0,1),(2,0,0),(0,1,0),(2,1,1),(0,2,0),(2,3,1)):
+        run(thr, 0, 1, cm, bbox, roots); torch.cuda.synchronize()
         cpe_amd.lib.profile(True)
-        for _ in range(3): run(thr, inv, conn8, cm, bbox, roots)
+        for _ in range(3): run(thr, 0, 1, cm, bbox, roots)
         torch.cuda.synchronize()
         rep = cpe_amd.lib.profile_report(); cpe_amd.lib.profile(False)
-        print(f'thr {thr} inv {inv} count {cm} bbox {bbox} roots {roots}: ' + ' '.join(f"{r[0].split('::')[-1][6:]}={r[2]/r[1]:.2f}ms" for r in rep))
+        st = ws.state()[0]
+        print(f'thr {thr} count {cm} bbox/rect {bbox} roots {roots} n_roots {st["n_roots"]}: ' + ' '.join(f"{r[0].split('::')[-1][6:]}={r[2]/r[1]:.2f}ms" for r in rep))
