@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, cpe_amd
 from cpe_amd import synth, api
-n = 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 b = synth.render_batch(n // 2, 1200, 1920, seed=1, device='cuda', with_gt=False)
 frames = torch.cat([b['left'], b['right']])
 ws = api.DetectWorkspace(n, 1200, 1920, frames.device)
@@ -12,7 +12,7 @@ L = cpe_amd.lib.load()
 def run(thr, inv, conn8, cm, bbox, roots):
     cpe_amd.lib.check(L.cpe_debug_ccl(cl.data_ptr(), n, 1200, 1920, thr, inv, conn8, cm, bbox, roots, ws.view.data_ptr(), ws.bytes, torch.cuda.current_stream().cuda_stream), 'ccl')
 print(ws.state()[0])
-for thr in (50, 60, 100, 200):
+for thr in (50, 100):
     for cm, bbox, roots in ((0,0,0),(0,0,1),(2,0,0),(0,1,0),(2,1,1),(0,2,0),(2,3,1)):
         run(thr, 0, 1, cm, bbox, roots); torch.cuda.synchronize()
         cpe_amd.lib.profile(True)
