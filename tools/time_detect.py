@@ -20,3 +20,7 @@ for it in range(3):
 print('status', det['status'].tolist(), 'npts', det['n'].tolist())
 print('fit status', out['status'].tolist(), 'm', out['m'].tolist(), 'iters', out['iters'][:, 0].tolist(), 'flags', out['flags'].tolist())
 print('fvals', out['fvals'].tolist())
+cpe_amd.lib.profile(True)
+det = api.detect_grid_batch(frames, ws); torch.cuda.synchronize()
+rep = cpe_amd.lib.profile_report(); cpe_amd.lib.profile(False)
+print('event profile:', ' | '.join(f"{r[0].split('::')[-1]} x{r[1]} {r[2]:.1f}ms" for r in rep[:10]))
