@@ -11,6 +11,7 @@
 // the hole's raster-first pixel and every outer border at the component's raster-first pixel, so the
 // parallel formulation visits exactly the borders the sequential raster scan does.
 #include "cpe_dev.h"
+#include <stdlib.h>
 
 namespace cpe {
 
@@ -498,7 +499,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 1, s)) != CPE_OK) return rc;          // working rectangle = whole frame
     for (int thr = 50; thr < 220; thr += 10) {
         // bright components (8-conn) inside the previous threshold's box: outer borders; accumulates this box
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 2, B.cnt, 1, B.nrect, st, s)) != CPE_OK) return rc;
+        static const int dbg = getenv("CPE_DEBUG_FG") ? atoi(getenv("CPE_DEBUG_FG")) : 0;   // timing experiments only
+        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, (dbg & 1) ? nullptr : B.roots, false, nullptr, (dbg & 2) ? 0 : 2, B.cnt,
+                          (dbg & 4) ? 0 : 1, (dbg & 8) ? nullptr : B.nrect, st, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
                     B.blob_d, B.dists);
         if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;      // working rectangle = box of the bright pixels
