@@ -18,6 +18,7 @@ namespace cpe {
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
             uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
+int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int invert, int *nrect, FrameState *st, hipStream_t s);
 
 namespace {
 
@@ -496,15 +497,14 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
-    if ((rc = ccl_ctl(st, B.nrect, n, h, w, 1, s)) != CPE_OK) return rc;          // working rectangle = whole frame
+    // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
+    // every brighter set and every hole of every binarisation lies inside it
+    if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
     for (int thr = 50; thr < 220; thr += 10) {
-        // bright components (8-conn) inside the previous threshold's box: outer borders; accumulates this box
-        static const int dbg = getenv("CPE_DEBUG_FG") ? atoi(getenv("CPE_DEBUG_FG")) : 0;   // timing experiments only
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, (dbg & 1) ? nullptr : B.roots, false, nullptr, (dbg & 2) ? 0 : 2, B.cnt,
-                          (dbg & 4) ? 0 : 1, (dbg & 8) ? nullptr : B.nrect, st, s)) != CPE_OK) return rc;
+        // bright components (8-conn): outer borders
+        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 2, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
                     B.blob_d, B.dists);
-        if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;      // working rectangle = box of the bright pixels
         // enclosed dark components (4-conn): hole borders
         if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, true, B.touch, 1, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
