@@ -44,6 +44,69 @@ __global__ __launch_bounds__(256) void k_morph_rect(const uint8_t *__restrict__ 
     dst[gi] = res ? 255 : 0;
 }
 
+// a-2 in one kernel: binary -> open(20x1) -> hmask, open(1x20) -> vmask, joints = hmask & vmask.
+// 64x32 output tile; the binary tile with a 20-px apron sits in LDS, erosions (anchor 10) and dilations run on it.
+constexpr int OT_X = 64, OT_Y = 32, OAP = 20;
+constexpr int OIN_W = OT_X + 2 * OAP, OIN_H = OT_Y + 2 * OAP;
+__global__ __launch_bounds__(256) void k_open20_joints(const uint8_t *__restrict__ bin, int h, int w, int tiles_x,
+                                                       int tiles_y, uint8_t *__restrict__ hm, uint8_t *__restrict__ vm,
+                                                       uint8_t *__restrict__ jm)
+{
+    __shared__ uint8_t s_in[OIN_H * OIN_W];          // 1 = foreground, 2 = outside the image
+    __shared__ uint8_t s_eh[OT_Y * (OT_X + 2 * 10)]; // eroded by 20x1 on columns [-10, OT_X+10)
+    __shared__ uint8_t s_ev[(OT_Y + 2 * 10) * OT_X]; // eroded by 1x20 on rows    [-10, OT_Y+10)
+    const int t = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
+    const int gx0 = (tt % tiles_x) * OT_X, gy0 = (tt / tiles_x) * OT_Y;
+    const size_t N = (size_t)h * w;
+    const uint8_t *im = bin + f * N;
+    for (int i = t; i < OIN_H * OIN_W; i += 256) {
+        int ry = i / OIN_W, rx = i - ry * OIN_W;
+        int y = gy0 - OAP + ry, x = gx0 - OAP + rx;
+        uint8_t v = 2;
+        if (x >= 0 && x < w && y >= 0 && y < h) v = im[(size_t)y * w + x] ? 1 : 0;
+        s_in[i] = v;
+    }
+    __syncthreads();
+    // erosion: all in-image pixels of the window [p-10, p+9] set (outside never erodes); outside positions -> 2
+    for (int i = t; i < OT_Y * (OT_X + 20); i += 256) {
+        int ry = i / (OT_X + 20), rx = i - ry * (OT_X + 20);
+        const uint8_t *p = &s_in[(ry + OAP) * OIN_W + (rx + OAP - 10)];   // centre (tile x = rx - 10)
+        uint8_t r = 2;
+        if (p[0] != 2) {
+            r = 1;
+            for (int k = -10; k <= 9; k++) if (p[k] == 0) { r = 0; break; }
+        }
+        s_eh[i] = r;
+    }
+    for (int i = t; i < (OT_Y + 20) * OT_X; i += 256) {
+        int ry = i / OT_X, rx = i - ry * OT_X;
+        const uint8_t *p = &s_in[(ry + OAP - 10) * OIN_W + (rx + OAP)];
+        uint8_t r = 2;
+        if (p[0] != 2) {
+            r = 1;
+            for (int k = -10; k <= 9; k++) if (p[k * OIN_W] == 0) { r = 0; break; }
+        }
+        s_ev[i] = r;
+    }
+    __syncthreads();
+    // dilation with the same offsets [p-10, p+9] (outside never dilates)
+    for (int i = t; i < OT_Y * OT_X; i += 256) {
+        int ry = i / OT_X, rx = i - ry * OT_X;
+        int y = gy0 + ry, x = gx0 + rx;
+        if (y >= h || x >= w) continue;
+        const uint8_t *ph = &s_eh[ry * (OT_X + 20) + rx + 10];
+        const uint8_t *pv = &s_ev[(ry + 10) * OT_X + rx];
+        bool dh = false, dv = false;
+        for (int k = -10; k <= 9; k++) { dh = dh || (ph[k] == 1); dv = dv || (pv[k * OT_X] == 1); }
+        size_t o = f * N + (size_t)y * w + x;
+        hm[o] = dh ? 255 : 0;
+        vm[o] = dv ? 255 : 0;
+        jm[o] = (dh && dv) ? 255 : 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_and2(const uint8_t *a, const uint8_t *b, size_t total, uint8_t *dst)
 {
     size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -706,11 +769,10 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s)
 {
     const size_t total = (size_t)h * w * n;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 20, 1, 0, B.tmpA);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 20, 1, 1, B.hmask);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.binary, total, h, w, 1, 20, 0, B.tmpA);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 1, 20, 1, B.vmask);
-    CPE_KLAUNCH(k_and2, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.vmask, total, B.joints_mask);
+    (void)total;
+    const int tiles_x = (w + OT_X - 1) / OT_X, tiles_y = (h + OT_Y - 1) / OT_Y;
+    CPE_KLAUNCH(k_open20_joints, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.binary, h, w, tiles_x,
+                tiles_y, B.hmask, B.vmask, B.joints_mask);
     CPE_CHECK_LAUNCH("joints_mask_stage");
     return CPE_OK;
 }
