@@ -150,6 +150,8 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     bool ok = trace_border(nz, x0, y0, is_hole != 0, sv, max_steps);
     if (!ok) { st[f].overflow = 1; return; }
     sv.finish();
+    atomicMax(&st[f].pad[is_hole ? 1 : 0], sv.npts);
+    atomicAdd(&st[f].pad[2], sv.npts);
     double m00, m10, m01;
     moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
     if (m00 < 10.0 || m00 >= 5000.0) return;
