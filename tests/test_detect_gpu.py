@@ -59,8 +59,9 @@ def _compare(cpe, orc, gpu, frames, check_planes=True, allow_overflow=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('h,w,seed', [(480, 640, 0), (600, 800, 4)])
+@pytest.mark.parametrize('h,w,seed', [(480, 640, 0), (600, 800, 4), (602, 801, 6), (483, 650, 8)])
 def test_detect_small_frames_stage_by_stage(cpe, orc, gpu, h, w, seed):
+    # 602x801 / 483x650: sizes that are not multiples of 4 (CLAHE pads with BORDER_REFLECT_101) nor of any tile size
     n_ok = _compare(cpe, orc, gpu, _frames(h, w, 2, seed))
     assert n_ok >= 2
 
