@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int TX = 64, TY = 64, NT = 512;
+constexpr int TX = 64, TY = 64, NT = 1024;
 constexpr int RA = 23, RB = 21, RG = 9, RE = 7;
 constexpr int AW = TX + 2 * RA, AH = TY + 2 * RA;   // 110
 constexpr int BW = TX + 2 * RB, BH = TY + 2 * RB;   // 106
