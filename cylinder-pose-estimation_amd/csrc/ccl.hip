@@ -38,7 +38,7 @@ __device__ __forceinline__ Rect get_rect(const FrameState *st, size_t f, int use
 
 __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ img, int rows_total, int h, int w,
                                                   int thr, int invert, const FrameState *__restrict__ st, int use_rect,
-                                                  int *__restrict__ L, int *__restrict__ cnt)
+                                                  int *__restrict__ L, int *__restrict__ cnt, int sparse)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
             unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
             int sx = m ? (x0 + 63 - __clzll(m)) : carry_start;
             L[base + x] = y * w + sx;
-        } else if (valid) {
-            L[base + x] = -1;
+        } else if (valid && !sparse) {
+            L[base + x] = -1;   // sparse passes never read labels of pixels outside the set
         }
         bool last_in = (b >> 63) & 1ull;
         if (last_in) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, in
 __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                     int invert, FrameState *__restrict__ st, int use_rect,
                                                     int *__restrict__ L, const uint8_t *__restrict__ touch, int count_mode,
-                                                    int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect)
+                                                    int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect, int sparse)
 {
     // grid = (ceil(N / 256), n): a workgroup never straddles two frames, so every wave-level aggregate below is
     // per frame
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
     if ((size_t)i < N) {
         y = i / w; x = i - y * w;
         const Rect r = get_rect(st, f, use_rect, h, w);
-        if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) {
+        if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) && (!sparse || pred(img + f * N, i, thr, invert))) {
             int v = L[gi];
             if (v >= 0) {
                 root = uf_find_c(L + f * N, v);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             }
         }
     }
-    if (count_mode) {
+    if (count_mode == 1 || count_mode == 2) {
         bool c = in && !touched;
         if (c && count_mode == 2) {
             const uint8_t *im = img + f * N;
@@ -290,9 +290,10 @@ int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int i
 
 // One labelling pass.  roots (optional): component list in st[].n_roots / roots; holes_only drops components
 // that reach the border of the working rectangle (needs `touch`); count_mode/cnt as in k_ccl_finish;
+// count_mode 3 only zeroes cnt inside the set's rectangle; sparse: labels of pixels outside the set are left untouched.
 // use_rect: restrict to st[].crect; nrect (optional, int[n][16]): accumulate the set's bounding box there.
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s)
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse)
 {
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
@@ -300,7 +301,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     CPE_LAUNCH_BEGIN();
     if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0);
     CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
-                count_mode ? cnt : (int *)nullptr);
+                count_mode ? cnt : (int *)nullptr, sparse);
     CPE_KLAUNCH(k_ccl_merge, dim3(gpx), dim3(256), 0, s, img, total, h, w, thr, invert, conn8, (const FrameState *)st, use_rect, L);
     if (holes_only) {
         (void)hipMemsetAsync(touch, 0, total, s);
@@ -309,7 +310,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
                     use_rect, touch);
     }
     CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
-                holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect);
+                holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;
 }

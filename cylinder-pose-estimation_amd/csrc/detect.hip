@@ -12,7 +12,7 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
@@ -33,7 +33,7 @@ struct Layout {
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_ROOTS2, P_NROOTS2, P_COUNT
 };
 
 static_assert(P_COUNT <= 48, "Layout arrays too small");
@@ -65,6 +65,10 @@ Layout make_layout(int n, int h, int w)
     per[P_HULL] = (size_t)4 * w * sizeof(int);
     per[P_LINES] = lines_ws_bytes();
     per[P_NRECT] = 16 * sizeof(int);
+    per[P_LAB2] = N * 4;
+    per[P_LAB3] = N * 4;
+    per[P_ROOTS2] = (size_t)MAXROOTS * sizeof(int);
+    per[P_NROOTS2] = sizeof(int);
     size_t o = 0;
     for (int i = 0; i < P_COUNT; i++) {
         L.off[i] = o;
@@ -136,7 +140,8 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     FrameState *st = PL(FrameState, P_STATE);
     RegionBuffers R;
     R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
-    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
+    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.lab2 = PL(int, P_LAB2); R.cnt2 = PL(int, P_LAB3); R.roots2 = PL(int, P_ROOTS2);
+    R.n_roots2 = PL(int, P_NROOTS2); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
     R.blobs = PL(BlobRec, P_BLOBS); R.blob_d = PL(int, P_BLOB_D); R.order = PL(int, P_ORDER); R.dists = PL(double, P_DISTS);
     R.groups = PL(Group, P_GROUPS); R.best = PL(unsigned long long, P_BEST); R.lohi = PL(int, P_LOHI); R.hull = PL(int, P_HULL);
     MaskBuffers M;

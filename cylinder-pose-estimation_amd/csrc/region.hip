@@ -16,7 +16,7 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int invert, int *nrect, FrameState *st, hipStream_t s);
 
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     if (k >= nr) return;
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
-    if (cnt[f * N + root] >= 5000) return;   // exact prune: polygon area >= pixel count bound >= maxArea
+    // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
+    // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
+    if (cnt[f * N + root] >= 5000) return;
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
     ThreshPred nz{cl + f * N, w, h, thr};
@@ -266,6 +268,26 @@ __global__ __launch_bounds__(64) void k_blob_merge(FrameState *__restrict__ st, 
         __syncthreads();
     }
     if (lane == 0) { S.n_groups = ng; S.n_blobs = 0; S.n_dists = 0; }
+}
+
+// enclosed-hole pixel totals per bright component: encl[label of the pixel west of the hole's first pixel] += |hole|
+__global__ __launch_bounds__(64) void k_enclosed(const int *__restrict__ hole_roots, const int *__restrict__ n_hole_roots,
+                                                 const int *__restrict__ cnt_bg, const int *__restrict__ Lfg, int h, int w,
+                                                 int *__restrict__ encl)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(n_hole_roots[f], MAXROOTS)) return;
+    const size_t N = (size_t)h * w;
+    const int hr = hole_roots[(size_t)f * MAXROOTS + k];
+    const int c = Lfg[f * N + hr - 1];      // flattened label of the bright pixel west of the hole
+    if (c >= 0) atomicAdd(&encl[f * N + c], min(cnt_bg[f * N + hr], 5000));
+}
+
+__global__ void k_save_roots(const FrameState *st, int n, int *n_hole_roots)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) n_hole_roots[f] = st[f].n_roots;
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -503,13 +525,16 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     // every brighter set and every hole of every binarisation lies inside it
     if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
     for (int thr = 50; thr < 220; thr += 10) {
-        // bright components (8-conn): outer borders
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 2, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt, st, B.blobs,
+        // enclosed dark components (4-conn): hole borders; pixel counts in B.cnt
+        if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots2, true, B.touch, 1, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_save_roots, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameState *)st, n, B.n_roots2);
+        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots2, B.cnt, st, B.blobs,
                     B.blob_d, B.dists);
-        // enclosed dark components (4-conn): hole borders
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, true, B.touch, 1, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots, B.cnt, st, B.blobs,
+        // bright components (8-conn): outer borders; B.cnt2 = pixels of the holes each one encloses
+        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab2, B.roots, false, nullptr, 3, B.cnt2, 1, nullptr, st, s, 1)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_enclosed, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const int *)B.roots2, (const int *)B.n_roots2,
+                    (const int *)B.cnt, (const int *)B.lab2, h, w, B.cnt2);
+        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt2, st, B.blobs,
                     B.blob_d, B.dists);
         CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
         CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
