@@ -31,12 +31,25 @@ ALGO_BYTES_PER_PX = {
     'k_preprocess': 2.0,        # u8 frame in, u8 mask out
     'k_ccl_init': 5.0,          # u8 image in, i32 label out
     'k_ccl_merge': 5.0,         # u8 image in, i32 labels read (unions touch few of them)
-    'k_ccl_flatten': 8.0,       # i32 labels in, i32 labels out
-    'k_ccl_count': 5.0,         # i32 labels + u8 image in
-    'k_collect_roots': 4.0,     # i32 labels in
+    'k_ccl_finish': 9.0,        # u8 image + i32 labels in, i32 labels out
     'k_morph_rect': 2.0,        # u8 in, u8 out
     'k_blur_h': 3.0, 'k_blur_v': 3.0, 'k_clahe_apply': 2.0, 'k_and2': 3.0, 'k_and3': 4.0, 'k_or_and': 4.0,
 }
+
+
+def pmc_traffic(kernel, images_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same
+    pipeline (profiles/r01_pmc_summary.csv, bytes per launch at 64 images per launch; tools/pmc.sh), scaled to this
+    launch size.  Byte-granular loads: FETCH_SIZE taken as reported (the guide's x2 applies to 16-B streaming reads)."""
+    fn = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.csv')
+    if not os.path.exists(fn):
+        return None
+    import csv
+    for r in csv.DictReader(open(fn)):
+        if r['kernel'] == kernel:
+            per64 = float(r['fetch_KiB_per_launch_raw']) * 1024 + float(r['write_bytes_per_launch'])
+            return per64 * images_per_launch / float(r.get('images_per_launch', 64))
+    return None
 
 
 def cpu_baseline(left, right, K1, K2, T21, radius, budget_s=20.0):
@@ -128,11 +141,16 @@ def main():
         bpp = ALGO_BYTES_PER_PX.get(short)
         if bpp is None:      # irregular kernel (border tracing ...): it has to see each frame's pixels at most once
             bpp = 1.0
+        if short.startswith('k_ccl_'):
+            # 34 of the 41 labelling passes per image only work inside the blob detector's rectangle
+            st = pipe._ws(2 * c).state()
+            rect_px = float(np.mean([max(0, s_['crect2'] - s_['crect0'] + 1) * max(0, s_['crect3'] - s_['crect1'] + 1) for s_ in st]))
+            px_per_launch = 2 * c * (34 * rect_px + 7 * H * W) / 41
         algo = bpp * px_per_launch
         avg_s = ms / calls / 1e3
         roof = dict(bound='hbm', kernel=short, calls_per_chunk=calls, avg_launch_ms=ms / calls, share_of_gpu_time=ms / tot,
                     algorithmic_bytes_per_launch=algo, achieved=algo / avg_s / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                    frac=(algo / avg_s) / HBM_PEAK, traffic=None,
+                    frac=(algo / avg_s) / HBM_PEAK, traffic=pmc_traffic(short, 2 * c),
                     top5=[dict(kernel=r[0].split('::')[-1], calls=r[1], ms=round(r[2], 3)) for r in rep[:5]])
 
     if rank == 0:
