@@ -81,6 +81,8 @@ def main():
     ap.add_argument('--frames', type=int, default=4096, help='stereo frames per GPU per step')
     ap.add_argument('--chunk', type=int, default=128, help='stereo frames per kernel batch (workspace size)')
     ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes per GPU (cycled with fresh noise)')
+    ap.add_argument('--fit-mode', choices=['nm', 'lm'], default='nm',
+                    help='nm = fminsearch clone (reference behaviour, default); lm = Levenberg-Marquardt fast mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -109,7 +111,8 @@ def main():
                 nz = torch.randint(-1, 2, (k, H, W), generator=g, device=dev, dtype=torch.int16)
                 nz = nz * (torch.randint(0, 3, (k, H, W), generator=g, device=dev, dtype=torch.int16) == 0)
                 dst[i0:i0 + k] = (src[:k].to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
-    pipe = pipeline.FramePipeline(H, W, K1, K2, T21, radius, chunk=args.chunk, device=dev)
+    pipe = pipeline.FramePipeline(H, W, K1, K2, T21, radius, chunk=args.chunk, device=dev,
+                                  fit_mode=1 if args.fit_mode == 'lm' else 0)
 
     def step():
         rec = pipe.run(left, right)
@@ -163,7 +166,7 @@ def main():
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                    config=dict(workload=f'{F}-frame {W}x{H} stereo batch per GPU, full detect (both images) + chooseIdx + '
                                         f'triangulate + fitCylinderWPts3 Nelder-Mead (BASELINE.json configs[2])',
-                               frames_per_gpu=F, chunk=args.chunk, unique_scenes=U,
+                               frames_per_gpu=F, chunk=args.chunk, unique_scenes=U, fit_mode=args.fit_mode,
                                parallelism=f'frames sharded x{world}, all_gather of 128-B pose records'),
                    frames_ok_fraction=ok, mean_points_per_frame=float(n_pts.float().mean().item()),
                    path_hbm_frac=value * BYTES_PER_FRAME / HBM_PEAK / world,

@@ -474,6 +474,7 @@ __device__ __forceinline__ double eps_of(double x)  // MATLAB eps(x)
     return ldexp(1.0, e - 53);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ X, const int *__restrict__ cnt,
                                                      double R, double tolx, double tolf, int maxiter,
                                                      int maxfun, double *__restrict__ o_raw,
@@ -631,6 +632,9 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
     }
     const double f0 = cyl_objective(x0, P, R, lane);
 
+    double xf[6], ffinal;
+    int itercount, func_evals;
+    if constexpr (MODE == 0) {
     // ---- fminsearch (MATLAB order).  simplex is wave-uniform, kept in registers.
     constexpr int N = 6;
     double v[N + 1][N], fv[N + 1];
@@ -645,7 +649,8 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
         else v[j + 1][j] = 0.00025;
         fv[j + 1] = cyl_objective(v[j + 1], P, R, lane);
     }
-    int func_evals = N + 1, itercount = 1;
+    func_evals = N + 1;
+    itercount = 1;
 #define CSWAPV(a)                                                                       \
     if (fv[a] > fv[a + 1]) {                                                            \
         double t_ = fv[a]; fv[a] = fv[a + 1]; fv[a + 1] = t_;                           \
@@ -744,6 +749,114 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
 #undef SORT_SIMPLEX
 #undef CSWAPV
 
+#pragma unroll
+    for (int k = 0; k < 6; k++) xf[k] = v[0][k];
+    ffinal = fv[0];
+    } else {
+    // ---- Levenberg-Marquardt on the same objective (north_star's "Gauss-Newton/LM inner loop"; NOT what the
+    // reference runs -- fitCylinderWPts3.m:38 uses fminsearch -- validated against the Nelder-Mead result).
+    // r_i = d_i - R;  dr/do = -e/d;  dr/dv = -(alpha/d) e  with  e = (P-o) - v alpha, alpha = ((P-o).v)/|v|^2.
+    // The 6-parameter form has two gauge directions (origin along the axis, |v|): the damping term handles them.
+    double x[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) x[k] = x0[k];
+    double fx = f0, lambda = 1e-3;
+    itercount = 0;
+    func_evals = 1;
+    for (; itercount < maxiter && itercount < 200;) {
+        double A[21], g[6];
+#pragma unroll
+        for (int k = 0; k < 21; k++) A[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] = 0.0;
+        {
+            double p2[3] = {x[0] + x[3], x[1] + x[4], x[2] + x[5]};
+            double vv[3] = {p2[0] - x[0], p2[1] - x[1], p2[2] - x[2]};
+            double nv2 = (vv[0] * vv[0] + vv[1] * vv[1]) + vv[2] * vv[2];
+            for (int k = lane; k < n; k += 64) {
+                const double *pt = sP + 3 * k;
+                double al = (((pt[0] - x[0]) * vv[0] + (pt[1] - x[1]) * vv[1]) + (pt[2] - x[2]) * vv[2]) / nv2;
+                double e[3] = {pt[0] - (x[0] + vv[0] * al), pt[1] - (x[1] + vv[1] * al), pt[2] - (x[2] + vv[2] * al)};
+                double dd = sqrt((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+                if (dd > 0) {
+                    double r = dd - R, c1 = -1.0 / dd, c2 = -(al / dd);
+                    double j[6] = {c1 * e[0], c1 * e[1], c1 * e[2], c2 * e[0], c2 * e[1], c2 * e[2]};
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int b = a; b < 6; b++) { A[q] = A[q] + j[a] * j[b]; q++; }
+                        g[a] = g[a] + j[a] * r;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 21; k++) A[k] = wave_sum(A[k]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) g[k] = wave_sum(g[k]);
+        }
+        itercount++;
+        bool accepted = false;
+        double dmax = 0, fprev = fx;
+        for (int tr = 0; tr < 12 && !accepted; tr++) {
+            double M[36], rhs[6], dl[6];
+            {
+                int q = 0;
+                double trA = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++) { M[a * 6 + b] = A[q]; M[b * 6 + a] = A[q]; if (a == b) trA = trA + A[q]; q++; }
+#pragma unroll
+                for (int a = 0; a < 6; a++) { M[a * 6 + a] = M[a * 6 + a] + lambda * M[a * 6 + a] + 1e-12 * trA; rhs[a] = -g[a]; }
+            }
+            // Gaussian elimination with partial pivoting (wave-uniform)
+            bool singular = false;
+            for (int c = 0; c < 6; c++) {
+                int pv = c;
+                for (int r = c + 1; r < 6; r++)
+                    if (fabs(M[r * 6 + c]) > fabs(M[pv * 6 + c])) pv = r;
+                if (M[pv * 6 + c] == 0) { singular = true; break; }
+                if (pv != c) {
+                    for (int k = 0; k < 6; k++) { double t_ = M[c * 6 + k]; M[c * 6 + k] = M[pv * 6 + k]; M[pv * 6 + k] = t_; }
+                    double t_ = rhs[c]; rhs[c] = rhs[pv]; rhs[pv] = t_;
+                }
+                for (int r = c + 1; r < 6; r++) {
+                    double fct = M[r * 6 + c] / M[c * 6 + c];
+                    for (int k = c; k < 6; k++) M[r * 6 + k] = M[r * 6 + k] - fct * M[c * 6 + k];
+                    rhs[r] = rhs[r] - fct * rhs[c];
+                }
+            }
+            if (singular) { lambda = lambda * 10; continue; }
+            for (int r = 5; r >= 0; r--) {
+                double sacc = rhs[r];
+                for (int k = r + 1; k < 6; k++) sacc = sacc - M[r * 6 + k] * dl[k];
+                dl[r] = sacc / M[r * 6 + r];
+            }
+            double xn[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) xn[k] = x[k] + dl[k];
+            double fn = cyl_objective(xn, P, R, lane);
+            func_evals++;
+            if (fn < fx) {
+                dmax = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { dmax = fmax(dmax, fabs(dl[k])); x[k] = xn[k]; }
+                fx = fn;
+                lambda = fmax(lambda / 10, 1e-12);
+                accepted = true;
+            } else {
+                lambda = lambda * 10;
+            }
+        }
+        if (!accepted) break;
+        if ((fprev - fx) <= tolf * 1e-3 * (1.0 + fx) && dmax <= tolx) break;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) xf[k] = x[k];
+    ffinal = fx;
+    }
+
     // applyCylParamsPrior.m on both rows, cylParams2T.m on the final row
     double ymin = DBL_MAX;
     for (int k = lane; k < n; k += 64) ymin = fmin(ymin, sP[3 * k + 1]);
@@ -751,7 +864,7 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
     for (int off = 32; off >= 1; off >>= 1) ymin = fmin(ymin, __shfl_xor(ymin, off, 64));
     if (lane == 0) {
         double rows[2][6];
-        for (int k = 0; k < 6; k++) { rows[0][k] = x0[k]; rows[1][k] = v[0][k]; }
+        for (int k = 0; k < 6; k++) { rows[0][k] = x0[k]; rows[1][k] = xf[k]; }
         for (int rI = 0; rI < 2; rI++) {
             for (int k = 0; k < 6; k++) o_raw[12 * f + 6 * rI + k] = rows[rI][k];
             double o[3] = {rows[rI][0], rows[rI][1], rows[rI][2]}, d[3] = {rows[rI][3], rows[rI][4], rows[rI][5]};
@@ -775,7 +888,7 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
         for (int r = 0; r < 3; r++) { T[r * 4] = xv[r]; T[r * 4 + 1] = y[r]; T[r * 4 + 2] = z[r]; T[r * 4 + 3] = cy[r]; }
         T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
         o_fvals[2 * f] = f0;
-        o_fvals[2 * f + 1] = fv[0];
+        o_fvals[2 * f + 1] = ffinal;
         o_iters[2 * f] = itercount;
         o_iters[2 * f + 1] = func_evals;
         o_status[f] = CPE_ST_OK;
@@ -820,14 +933,19 @@ extern "C" int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, i
 {
     CPE_CHECK_ARG(X && cnt && cyl_raw && cyl && T && fvals && iters && status, "cpe_fit_cylinder_batch: null pointer");
     CPE_CHECK_ARG(n >= 0, "cpe_fit_cylinder_batch: n < 0");
-    CpeFitParams p = {1e-5, 1e-5, 100000, 100000};
+    CpeFitParams p = {1e-5, 1e-5, 100000, 100000, CPE_FIT_NELDER_MEAD, 0};
     if (params) p = *params;
     CPE_CHECK_ARG(p.tol_x >= 0 && p.tol_f >= 0 && p.max_iter > 0 && p.max_fun_evals > 0,
                   "cpe_fit_cylinder_batch: bad CpeFitParams");
     if (n == 0) return CPE_OK;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_fit_cylinder, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f,
-                       p.max_iter, p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
+    CPE_CHECK_ARG(p.mode == CPE_FIT_NELDER_MEAD || p.mode == CPE_FIT_LM, "cpe_fit_cylinder_batch: unknown mode %d", p.mode);
+    if (p.mode == CPE_FIT_LM)
+        CPE_KLAUNCH(k_fit_cylinder<1>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
+                    p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
+    else
+        CPE_KLAUNCH(k_fit_cylinder<0>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
+                    p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
     CPE_CHECK_LAUNCH("k_fit_cylinder");
     return CPE_OK;
 }

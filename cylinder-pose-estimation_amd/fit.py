@@ -69,7 +69,10 @@ def select_triangulate_batch(gp1: GridTables, gp2: GridTables, K1, K2, T21, sele
     return dict(p1=p1, p2=p2, idx=idx, pts3=X, err=err, m=m, mean_err=me, flags=flags, _ws=ws)
 
 
-def fit_cylinder_batch(pts3, cnt, radius, tol_x=1e-5, tol_f=1e-5, max_iter=100000, max_fun_evals=100000):
+FIT_NELDER_MEAD, FIT_LM = 0, 1
+
+
+def fit_cylinder_batch(pts3, cnt, radius, tol_x=1e-5, tol_f=1e-5, max_iter=100000, max_fun_evals=100000, mode=FIT_NELDER_MEAD):
     """fitCylinderWPts3 + applyCylParamsPrior + cylParams2T (fitSingleCylinder.m:20-25)"""
     L = _lib.load()
     dev = pts3.device
@@ -78,7 +81,7 @@ def fit_cylinder_batch(pts3, cnt, radius, tol_x=1e-5, tol_f=1e-5, max_iter=10000
     T = torch.zeros((n, 4, 4), dtype=torch.float64, device=dev)
     fv = torch.zeros((n, 2), dtype=torch.float64, device=dev)
     it = torch.zeros((n, 2), dtype=torch.int32, device=dev); st = torch.zeros(n, dtype=torch.int32, device=dev)
-    prm = _lib.CpeFitParams(tol_x, tol_f, max_iter, max_fun_evals)
+    prm = _lib.CpeFitParams(tol_x, tol_f, max_iter, max_fun_evals, mode, 0)
     _lib.check(L.cpe_fit_cylinder_batch(pts3.data_ptr(), cnt.data_ptr(), n, float(radius), C.addressof(prm),
                                         raw.data_ptr(), cyl.data_ptr(), T.data_ptr(), fv.data_ptr(), it.data_ptr(),
                                         st.data_ptr(), _stream()), 'cpe_fit_cylinder_batch')

@@ -43,7 +43,8 @@ _SIGS = {
 
 
 class CpeFitParams(C.Structure):
-    _fields_ = [('tol_x', C.c_double), ('tol_f', C.c_double), ('max_iter', C.c_int32), ('max_fun_evals', C.c_int32)]
+    _fields_ = [('tol_x', C.c_double), ('tol_f', C.c_double), ('max_iter', C.c_int32), ('max_fun_evals', C.c_int32),
+                ('mode', C.c_int32), ('reserved', C.c_int32)]
 
 
 MAXP = 1024

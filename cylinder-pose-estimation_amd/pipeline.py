@@ -30,10 +30,11 @@ def unpack_counters(code):
 class FramePipeline:
     """reusable workspaces for chunks of `chunk` stereo frames of size h x w"""
 
-    def __init__(self, h, w, K1, K2, T21, radius, chunk=64, device='cuda:0', selector=fit.SEL_CHOOSE_IDX, th=0.3):
+    def __init__(self, h, w, K1, K2, T21, radius, chunk=64, device='cuda:0', selector=fit.SEL_CHOOSE_IDX, th=0.3,
+                 fit_mode=fit.FIT_NELDER_MEAD):
         self.h, self.w, self.chunk, self.device = h, w, chunk, torch.device(device)
         self.K1, self.K2, self.T21, self.radius = K1, K2, T21, radius
-        self.selector, self.th = selector, th
+        self.selector, self.th, self.fit_mode = selector, th, fit_mode
         self.ws = {}
 
     def _ws(self, n_img):
@@ -47,7 +48,8 @@ class FramePipeline:
         det = api.detect_grid_batch(frames, self._ws(2 * c))
         g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
         g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
-        out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th)
+        out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th,
+                                            mode=self.fit_mode)
         rec = torch.empty((c, REC), dtype=torch.float64, device=frames.device)
         rec[:, 0:6] = out['cyl'][:, 0]
         rec[:, 6:12] = out['cyl'][:, 1]

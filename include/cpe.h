@@ -154,7 +154,11 @@ typedef struct CpeFitParams {
     double tol_f;          /* fminsearch TolFun (1e-5) */
     int32_t max_iter;      /* MaxIter (1e5) */
     int32_t max_fun_evals; /* MaxFunEvals (1e5) */
+    int32_t mode;          /* CPE_FIT_NELDER_MEAD (reference behaviour, default) or CPE_FIT_LM */
+    int32_t reserved;      /* 0 */
 } CpeFitParams;
+#define CPE_FIT_NELDER_MEAD 0 /* fminsearch clone: what fitCylinderWPts3.m:38 runs */
+#define CPE_FIT_LM 1          /* Levenberg-Marquardt on the same objective (fast mode; not in the reference) */
 
 /* fitCylinderWPts3(pts3, radius) + applyCylParamsPrior + cylParams2T for n frames, one wavefront per
  * frame (fitSingleCylinder.m:20-25).  X f64[n,CPE_MAXP,3], cnt i32[n].  params NULL = reference values.

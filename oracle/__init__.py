@@ -134,13 +134,13 @@ def cyl_objective(x, P, R):
     return lib().orc_cyl_objective(_p(x, C.c_double), _p(P, C.c_double), len(P), C.c_double(R))
 
 
-def fit_cylinder(P, R, tolx=1e-5, tolf=1e-5, maxiter=100000, maxfun=100000):
-    """fitCylinderWPts3.m: P (n,3) -> dict(cyl0[6], cyl[6], fvals[2], iters, evals, status)"""
+def fit_cylinder(P, R, tolx=1e-5, tolf=1e-5, maxiter=100000, maxfun=100000, mode=0):
+    """fitCylinderWPts3.m: P (n,3) -> dict(cyl0[6], cyl[6], fvals[2], iters, evals, status); mode 1 = the build's LM"""
     P = _f64(P)
     cyl0 = np.empty(6); cyl = np.empty(6); fv = np.empty(2); it = C.c_int(0); ev = C.c_int(0)
-    st = lib().orc_fit_cylinder(_p(P, C.c_double), len(P), C.c_double(R), C.c_double(tolx), C.c_double(tolf),
-                                maxiter, maxfun, _p(cyl0, C.c_double), _p(cyl, C.c_double), _p(fv, C.c_double),
-                                C.byref(it), C.byref(ev))
+    st = lib().orc_fit_cylinder_mode(_p(P, C.c_double), len(P), C.c_double(R), C.c_double(tolx), C.c_double(tolf),
+                                     maxiter, maxfun, mode, _p(cyl0, C.c_double), _p(cyl, C.c_double), _p(fv, C.c_double),
+                                     C.byref(it), C.byref(ev))
     return dict(cyl0=cyl0, cyl=cyl, fvals=fv, iters=it.value, evals=ev.value, status=st)
 
 

@@ -474,6 +474,105 @@ static void nelder_mead6(const double *x0, const double *P, int n, double R, dou
     free(tmp);
 }
 
+/* Levenberg-Marquardt on the same objective -- restatement of the build's own fast mode (csrc/fit.hip),
+ * NOT of anything in the reference (fitCylinderWPts3.m:38 runs fminsearch).  Same operation order as the kernel. */
+static void lm6(const double *x0, double f0, const double *P, int n, double R, double tolx, double tolf, int maxiter,
+                double *xout, double *fout, int *iters, int *evals)
+{
+    double x[6], *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
+    double *cols = (double *)malloc((size_t)(n + 1) * 27 * sizeof(double));
+    memcpy(x, x0, sizeof x);
+    double fx = f0, lambda = 1e-3;
+    int itercount = 0, func_evals = 1;
+    for (; itercount < maxiter && itercount < 200;) {
+        double A[21], g[6];
+        {
+            double p2[3] = {x[0] + x[3], x[1] + x[4], x[2] + x[5]};
+            double vv[3] = {p2[0] - x[0], p2[1] - x[1], p2[2] - x[2]};
+            double nv2 = (vv[0] * vv[0] + vv[1] * vv[1]) + vv[2] * vv[2];
+            for (int k = 0; k < n; k++) {
+                const double *pt = P + 3 * k;
+                double *c = cols + (size_t)k * 27;
+                for (int q = 0; q < 27; q++) c[q] = 0.0;
+                double al = (((pt[0] - x[0]) * vv[0] + (pt[1] - x[1]) * vv[1]) + (pt[2] - x[2]) * vv[2]) / nv2;
+                double e[3] = {pt[0] - (x[0] + vv[0] * al), pt[1] - (x[1] + vv[1] * al), pt[2] - (x[2] + vv[2] * al)};
+                double dd = sqrt((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+                if (dd > 0) {
+                    double r = dd - R, c1 = -1.0 / dd, c2 = -(al / dd);
+                    double j[6] = {c1 * e[0], c1 * e[1], c1 * e[2], c2 * e[0], c2 * e[1], c2 * e[2]};
+                    int q = 0;
+                    for (int a = 0; a < 6; a++) {
+                        for (int b = a; b < 6; b++) { c[q] = j[a] * j[b]; q++; }
+                        c[21 + a] = j[a] * r;
+                    }
+                }
+            }
+            /* the kernel accumulates  acc = acc + term  per lane (skipping points with d == 0, whose terms are 0 here:
+             * adding +0.0 leaves every partial sum unchanged), then the 64-lane tree */
+            for (int q = 0; q < 27; q++) {
+                for (int k = 0; k < n; k++) tmp[k] = cols[(size_t)k * 27 + q];
+                double sres = sum64(tmp, n);
+                if (q < 21) A[q] = sres; else g[q - 21] = sres;
+            }
+        }
+        itercount++;
+        int accepted = 0;
+        double dmax = 0, fprev = fx;
+        for (int tr = 0; tr < 12 && !accepted; tr++) {
+            double M[36], rhs[6], dl[6];
+            {
+                int q = 0;
+                double trA = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int b = a; b < 6; b++) { M[a * 6 + b] = A[q]; M[b * 6 + a] = A[q]; if (a == b) trA = trA + A[q]; q++; }
+                for (int a = 0; a < 6; a++) { M[a * 6 + a] = M[a * 6 + a] + lambda * M[a * 6 + a] + 1e-12 * trA; rhs[a] = -g[a]; }
+            }
+            int singular = 0;
+            for (int c = 0; c < 6; c++) {
+                int pv = c;
+                for (int r = c + 1; r < 6; r++)
+                    if (fabs(M[r * 6 + c]) > fabs(M[pv * 6 + c])) pv = r;
+                if (M[pv * 6 + c] == 0) { singular = 1; break; }
+                if (pv != c) {
+                    for (int k = 0; k < 6; k++) { double t_ = M[c * 6 + k]; M[c * 6 + k] = M[pv * 6 + k]; M[pv * 6 + k] = t_; }
+                    double t_ = rhs[c]; rhs[c] = rhs[pv]; rhs[pv] = t_;
+                }
+                for (int r = c + 1; r < 6; r++) {
+                    double fct = M[r * 6 + c] / M[c * 6 + c];
+                    for (int k = c; k < 6; k++) M[r * 6 + k] = M[r * 6 + k] - fct * M[c * 6 + k];
+                    rhs[r] = rhs[r] - fct * rhs[c];
+                }
+            }
+            if (singular) { lambda = lambda * 10; continue; }
+            for (int r = 5; r >= 0; r--) {
+                double sacc = rhs[r];
+                for (int k = r + 1; k < 6; k++) sacc = sacc - M[r * 6 + k] * dl[k];
+                dl[r] = sacc / M[r * 6 + r];
+            }
+            double xn[6];
+            for (int k = 0; k < 6; k++) xn[k] = x[k] + dl[k];
+            double fn = cyl_objective(xn, P, n, R, tmp);
+            func_evals++;
+            if (fn < fx) {
+                dmax = 0;
+                for (int k = 0; k < 6; k++) { dmax = fmax(dmax, fabs(dl[k])); x[k] = xn[k]; }
+                fx = fn;
+                lambda = fmax(lambda / 10, 1e-12);
+                accepted = 1;
+            } else {
+                lambda = lambda * 10;
+            }
+        }
+        if (!accepted) break;
+        if ((fprev - fx) <= tolf * 1e-3 * (1.0 + fx) && dmax <= tolx) break;
+    }
+    memcpy(xout, x, sizeof x);
+    *fout = fx;
+    *iters = itercount;
+    *evals = func_evals;
+    free(tmp); free(cols);
+}
+
 /* solve M x = b (5x5), partial pivoting; M, b destroyed */
 static void solve5(double *M, double *b, double *x)
 {
@@ -571,8 +670,24 @@ static void est_curv_dir(const double *P, int n, int i, double *dir)
 }
 
 /* fitCylinderWPts3(Pts3, cylRadius): P is n x 3 (row = point). returns 0 ok, 5 too few points */
+static int fit_cylinder_mode(const double *P, int n, double R, double tolx, double tolf, int maxiter, int maxfun,
+                             int mode, double *cyl0, double *cyl, double *fvals, int *iters, int *evals);
+
 ORC_API int orc_fit_cylinder(const double *P, int n, double R, double tolx, double tolf, int maxiter,
                              int maxfun, double *cyl0, double *cyl, double *fvals, int *iters, int *evals)
+{
+    return fit_cylinder_mode(P, n, R, tolx, tolf, maxiter, maxfun, 0, cyl0, cyl, fvals, iters, evals);
+}
+
+/* mode 1 = Levenberg-Marquardt (the build's fast mode) */
+ORC_API int orc_fit_cylinder_mode(const double *P, int n, double R, double tolx, double tolf, int maxiter,
+                                  int maxfun, int mode, double *cyl0, double *cyl, double *fvals, int *iters, int *evals)
+{
+    return fit_cylinder_mode(P, n, R, tolx, tolf, maxiter, maxfun, mode, cyl0, cyl, fvals, iters, evals);
+}
+
+static int fit_cylinder_mode(const double *P, int n, double R, double tolx, double tolf, int maxiter, int maxfun,
+                             int mode, double *cyl0, double *cyl, double *fvals, int *iters, int *evals)
 {
     if (n < 3) return 5;
     double *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
@@ -605,7 +720,8 @@ ORC_API int orc_fit_cylinder(const double *P, int n, double R, double tolx, doub
         cyl0[3 + c] = dir0[c];
     }
     fvals[0] = cyl_objective(cyl0, P, n, R, tmp);
-    nelder_mead6(cyl0, P, n, R, tolx, tolf, maxiter, maxfun, cyl, &fvals[1], iters, evals);
+    if (mode == 1) lm6(cyl0, fvals[0], P, n, R, tolx, tolf, maxiter, cyl, &fvals[1], iters, evals);
+    else nelder_mead6(cyl0, P, n, R, tolx, tolf, maxiter, maxfun, cyl, &fvals[1], iters, evals);
     free(tmp);
     return 0;
 }

@@ -96,3 +96,33 @@ def test_fit_edge_cases(cpe, orc, gpu):
     assert int(out['m'][1]) == 0 and int(out['status'][1]) == 5
     assert int(out['status'][2]) == 5
     assert int(out['status'][0]) == 0
+
+
+@pytest.mark.gpu
+def test_lm_mode_bit_exact_and_close_to_nelder_mead(cpe, orc, gpu):
+    """the build's Levenberg-Marquardt fast mode (not in the reference): GPU == oracle restatement bit for bit;
+    its minimiser agrees with the Nelder-Mead (reference) answer where Nelder-Mead converged:
+    gauge-fixed axis direction within 1e-4 rad and f within 1e-6 relative -- the reference's own stopping tolerance
+    (TolX = TolFun = 1e-5) bounds how close two converged answers can be expected to be."""
+    from cpe_amd import fit
+    t1, t2, K1, K2, T21, fp, sc = make_tables(9, 8, noise=0.05, h=1200, w=1920)
+    g1 = fit.GridTables.from_lists(t1, gpu); g2 = fit.GridTables.from_lists(t2, gpu)
+    sel = fit.select_triangulate_batch(g1, g2, K1, K2, T21, selector=fit.SEL_JOIN)
+    nm = fit.fit_cylinder_batch(sel['pts3'], sel['m'], 45.0, mode=fit.FIT_NELDER_MEAD)
+    lm = fit.fit_cylinder_batch(sel['pts3'], sel['m'], 45.0, mode=fit.FIT_LM)
+    torch.cuda.synchronize()
+    close = 0
+    for i in range(len(t1)):
+        m = int(sel['m'][i]); X = sel['pts3'][i, :m].cpu().numpy()
+        ref = orc.fit_cylinder(X, 45.0, mode=1)
+        assert np.array_equal(lm['cyl_raw'][i, 1].cpu().numpy(), ref['cyl'])
+        assert np.array_equal(lm['fvals'][i].cpu().numpy(), ref['fvals'])
+        assert lm['iters'][i].tolist() == [ref['iters'], ref['evals']]
+        a = nm['cyl'][i, 1].cpu().numpy(); b = lm['cyl'][i, 1].cpu().numpy()
+        da = a[3:] / np.linalg.norm(a[3:]); db = b[3:] / np.linalg.norm(b[3:])
+        fa, fb = float(nm['fvals'][i, 1]), float(lm['fvals'][i, 1])
+        assert fb <= fa * (1 + 1e-9) + 1e-12                       # LM never ends above Nelder-Mead's value here
+        if np.arccos(np.clip(da @ db, -1, 1)) < 1e-4 and abs(fa - fb) <= 1e-6 * max(fa, 1e-12):
+            close += 1
+        assert int(lm['iters'][i, 0]) < 50
+    assert close >= 6, close
