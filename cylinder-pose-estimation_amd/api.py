@@ -17,7 +17,8 @@ from .fit import GridTables, MAXP
 PLANES = dict(binary=0, hmask=1, vmask=2, mask_contour=3, roi_h=4, roi_v=5, exp_h=6, exp_v=7, joints=8, state=9,
               clahe=10, blur19=11, blur7=12, labels=13)
 STATUS_TEXT = {0: 'ok', 1: 'no region (cv2.convexHull(None))', 2: 'no saturated spot (circle_radius0 unbound)',
-               3: 'no valid rows/cols', 4: 'empty point list', 5: 'too few points', 6: 'workspace capacity exceeded'}
+               3: 'no valid rows/cols', 4: 'empty point list', 5: 'too few points', 6: 'workspace capacity exceeded',
+               7: 'sub-pixel refinement raised (line sample above / left of the image)'}
 
 _STATE_FIELDS = ['status', 'rect0', 'rect1', 'rect2', 'rect3', 'r0', 'spot0', 'spot1', 'spot2', 'spot3', 'n_roots',
                  'n_comps', 'n_joints_all', 'n_joints', 'n_blobs', 'n_groups', 'n_groups_prev', 'n_kp', 'n_verts',
@@ -64,7 +65,7 @@ class DetectWorkspace:
         return out
 
 
-def detect_grid_batch(frames, ws=None):
+def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpixel_step=1.0):
     """frames: u8 tensor [n,h,w] on the GPU -> dict(xy f64[n,MAXP,2], id i32[n,MAXP,2], n i32[n], center f64[n,2],
     status i32[n], ws)"""
     if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3):
@@ -80,9 +81,11 @@ def detect_grid_batch(frames, ws=None):
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     center = torch.zeros((n, 2), dtype=torch.float64, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
-    _lib.check(L.cpe_detect_grid_batch(frames.data_ptr(), n, h, w, ws.view.data_ptr(), ws.bytes, xy.data_ptr(),
-                                       ids.data_ptr(), cnt.data_ptr(), center.data_ptr(), status.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream), 'cpe_detect_grid_batch')
+    prm = _lib.CpeDetectParams(1 if subpixel else 0, subpixel_window, subpixel_step)
+    _lib.check(L.cpe_detect_grid_batch_ex(frames.data_ptr(), n, h, w, C.addressof(prm), ws.view.data_ptr(), ws.bytes,
+                                          xy.data_ptr(), ids.data_ptr(), cnt.data_ptr(), center.data_ptr(),
+                                          status.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               'cpe_detect_grid_batch_ex')
     return dict(xy=xy, id=ids, n=cnt, center=center, status=status, ws=ws)
 
 

@@ -8,6 +8,7 @@
 // caller-supplied workspace (cpe_detect_workspace_bytes), laid out plane-major so that every kernel
 // streams [n, h, w] planes with fully coalesced accesses.
 #include "cpe_dev.h"
+#include <algorithm>
 
 namespace cpe {
 
@@ -20,7 +21,8 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
 int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, int h, int w, const int *joints,
-                FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, hipStream_t s);
+                FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
+                int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s);
 
 namespace {
 
@@ -33,7 +35,7 @@ struct Layout {
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_ROOTS2, P_NROOTS2, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_ROOTS2, P_NROOTS2, P_SUBPIX, P_COUNT
 };
 
 static_assert(P_COUNT <= 48, "Layout arrays too small");
@@ -69,6 +71,7 @@ Layout make_layout(int n, int h, int w)
     per[P_LAB3] = N * 4;
     per[P_ROOTS2] = (size_t)MAXROOTS * sizeof(int);
     per[P_NROOTS2] = sizeof(int);
+    per[P_SUBPIX] = (size_t)2 * MAXL * 2 * (size_t)(std::max(h, w) + 128) * sizeof(float);
     size_t o = 0;
     for (int i = 0; i < P_COUNT; i++) {
         L.off[i] = o;
@@ -124,6 +127,17 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
                                          double *xy, int32_t *id, int32_t *n_pts, double *center, int32_t *status,
                                          void *stream)
 {
+    return cpe_detect_grid_batch_ex(gray, n, h, w, nullptr, ws, ws_bytes, xy, id, n_pts, center, status, stream);
+}
+
+extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
+                                            void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
+                                            double *center, int32_t *status, void *stream)
+{
+    CpeDetectParams prm = {0, 7, 1.0};
+    if (params) prm = *params;
+    CPE_CHECK_ARG(prm.subpixel == 0 || (prm.subpixel_window >= 1 && prm.subpixel_window <= 13 && prm.subpixel_step > 0),
+                  "cpe_detect_grid_batch_ex: bad sub-pixel parameters");
     CPE_CHECK_ARG(gray && xy && id && n_pts && center && status, "cpe_detect_grid_batch: null pointer");
     CPE_CHECK_ARG(n >= 0 && h >= 64 && w >= 64 && h <= 4096 && w <= 4096,
                   "cpe_detect_grid_batch: need n>=0 and 64 <= h,w <= 4096 (got %d,%d,%d)", n, h, w);
@@ -164,7 +178,8 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
     if ((rc = blur7_u8(gray, n, h, w, M.tmp16, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
     if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
-                          n_pts, center, s)) != CPE_OK)
+                          n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
+                          std::max(h, w) + 128, s)) != CPE_OK)
         return rc;
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);

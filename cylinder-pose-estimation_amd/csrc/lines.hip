@@ -105,6 +105,108 @@ __device__ bool poly_intersection(const double *a, const double *b, double &xs, 
     return false;
 }
 
+// ---- row f-4: grey-level centre-of-gravity refinement of the fitted lines (util_cylinder.py:706-971) --------------
+// numpy's summation of <= 8 values: sequential below 8, the 8-way tree at 8
+__device__ float sum_f32_np(const float *a, int n)
+{
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    float res = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int i = 8; i < n; i++) res += a[i];
+    return res;
+}
+__device__ double sum_f64_np(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double res = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int i = 8; i < n; i++) res += a[i];
+    return res;
+}
+
+// compute_center_of_gravity_x / _y for one sample; returns true where the reference raises
+__device__ bool cog_refine(const uint8_t *gray, int h, int w, int half, bool along_y, double fixed, double moving, double &out)
+{
+    const int L = along_y ? h : w, Lf = along_y ? w : h;
+    int ifx = (int)rint(fixed);
+    int lo = (int)floor(moving) - half, hi = (int)ceil(moving) + half + 1;
+    if (lo < 0) lo = 0;
+    if (hi > L) hi = L;
+    out = moving;
+    if (ifx < 0 || ifx >= Lf) return false;
+    if (hi < 0) {
+        int wrapped = L + hi;
+        int len_roi = wrapped > lo ? wrapped - lo : 0;
+        return len_roi != 0;
+    }
+    int n = hi > lo ? hi - lo : 0;
+    if (n == 0) return false;
+    float G[16];
+    double prod[16];
+    if (n > 16) n = 16;
+    for (int k = 0; k < n; k++) {
+        int idx = lo + k;
+        uint8_t v = along_y ? gray[(size_t)idx * w + ifx] : gray[(size_t)ifx * w + idx];
+        G[k] = (float)((double)v * (1.0 / 255));
+    }
+    float s = sum_f32_np(G, n);
+    if (s == 0) return false;
+    for (int k = 0; k < n; k++) prod[k] = (double)(lo + k) * (double)G[k];
+    double cog = sum_f64_np(prod, n) / (double)s;
+    double delta = cog - moving;
+    if (fabs(delta) > 0.5) delta = delta > 0 ? 0.5 : -0.5;
+    double nv = moving + delta;
+    if (nv < 0) nv = 0;
+    if (nv > L - 1) nv = L - 1;
+    out = nv;
+    return false;
+}
+
+// np.polyfit(x, y, 2) in streaming form (column norms, then Givens rotations of the scaled rows)
+__device__ void polyfit2_stream(const float *xs, const float *ys, int n, double *coef)
+{
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int i = 0; i < n; i++) {
+        double x = (double)xs[i], x2 = x * x;
+        s0 += x2 * x2; s1 += x * x; s2 += 1.0;
+    }
+    double sc[3] = {sqrt(s0), sqrt(s1), sqrt(s2)};
+    double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, c[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        double x = (double)xs[i];
+        double row[3] = {(x * x) / sc[0], x / sc[1], 1.0 / sc[2]}, rhs = (double)ys[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (row[k] == 0) continue;
+            double a = R[k][k], b = row[k];
+            double r = sqrt(a * a + b * b);
+            double cg = a / r, sg = b / r;
+#pragma unroll
+            for (int j = k; j < 3; j++) {
+                double t = cg * R[k][j] + sg * row[j];
+                row[j] = -sg * R[k][j] + cg * row[j];
+                R[k][j] = t;
+            }
+            double t = cg * c[k] + sg * rhs;
+            rhs = -sg * c[k] + cg * rhs;
+            c[k] = t;
+        }
+    }
+    double z[3];
+    for (int r = 2; r >= 0; r--) {
+        double s = c[r];
+        for (int k = r + 1; k < 3; k++) s -= R[r][k] * z[k];
+        z[r] = s / R[r][r];
+    }
+    for (int k = 0; k < 3; k++) coef[k] = z[k] / sc[k];
+}
+
 // stable insertion sort of an index list by key (ascending)
 __device__ void sort_by_key(int *ord, int n, const double *key)
 {
@@ -120,7 +222,9 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                                                const uint8_t *__restrict__ g7, int h, int w,
                                                const int *__restrict__ joints, FrameState *__restrict__ st,
                                                LinesWS *__restrict__ wsall, double *__restrict__ o_xy,
-                                               int *__restrict__ o_id, int *__restrict__ o_n, double *__restrict__ o_center)
+                                               int *__restrict__ o_id, int *__restrict__ o_n, double *__restrict__ o_center,
+                                               const uint8_t *__restrict__ gray, int subpixel, int sp_window, double sp_step,
+                                               float *__restrict__ sp_scratch, int sp_cap)
 {
     const int f = blockIdx.x, t = threadIdx.x;
     FrameState &S = st[f];
@@ -212,6 +316,67 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     }
     __syncthreads();
     const int nr = s_n[0], nc = s_n[1];
+    if (subpixel) {
+        // modify_grayscale_Cline(gray, rows, cols, degree 2, sample_step, window): sample every fitted line, pull each
+        // sample to the grey-level centre of gravity across the line, re-fit.  Samples of line l live in
+        // sp_scratch[(f * 2*MAXL + l) * 2 * sp_cap ...] as float32 (abscissa | refined ordinate), as the reference stores them.
+        __shared__ int s_raise, s_K[2 * MAXL];
+        if (t == 0) s_raise = 0;
+        const int half = sp_window / 2;
+        const uint8_t *gimg = gray + f * N;
+        float *sbase = sp_scratch + (size_t)f * 2 * MAXL * 2 * sp_cap;
+        if (t < 128) {
+            const int sd = t >> 6, pos = t & 63;
+            int K = 0;
+            if (pos < s_n[sd]) {
+                const double *eq = W.eq[sd][s_ord[sd][pos]];
+                if (!(eq[4] < eq[3])) {
+                    double cntd = ceil(((eq[4] + 0.0001) - eq[3]) / sp_step);
+                    K = cntd > 0 ? (cntd > (double)sp_cap ? sp_cap + 1 : (int)cntd) : 0;
+                }
+            }
+            s_K[t] = K;
+        }
+        __syncthreads();
+        for (int l = 0; l < 128; l++) {
+            const int sd = l >> 6, pos = l & 63;
+            const int K = s_K[l];
+            if (K == 0) continue;
+            if (K > sp_cap) { if (t == 0) s_ovf = 1; continue; }
+            const double *eq = W.eq[sd][s_ord[sd][pos]];
+            const double lo = eq[3];
+            const double delta = (lo + sp_step) - lo;
+            float *xs = sbase + (size_t)l * 2 * sp_cap, *ys = xs + sp_cap;
+            for (int i = t; i < K; i += 256) {
+                double tt = i == 0 ? lo : (i == 1 ? lo + sp_step : lo + i * delta);
+                double u = ((0.0 * tt + eq[0]) * tt + eq[1]) * tt + eq[2];
+                double ref;
+                if (cog_refine(gimg, h, w, half, sd == 0, tt, u, ref)) s_raise = 1;
+                xs[i] = (float)tt;
+                ys[i] = (float)ref;
+            }
+        }
+        __syncthreads();
+        if (s_raise) {
+            if (t == 0) S.status = CPE_ST_SUBPIXEL_RAISED;
+            return;
+        }
+        if (t < 128) {
+            const int K = s_K[t];
+            if (K >= 3 && K <= sp_cap) {
+                const int sd = t >> 6, pos = t & 63;
+                double *eq = W.eq[sd][s_ord[sd][pos]];
+                const float *xs = sbase + (size_t)t * 2 * sp_cap, *ys = xs + sp_cap;
+                double c[3];
+                polyfit2_stream(xs, ys, K, c);
+                float mn = xs[0], mx = xs[0];
+                for (int i = 1; i < K; i++) { mn = fminf(mn, xs[i]); mx = fmaxf(mx, xs[i]); }
+                eq[0] = c[0]; eq[1] = c[1]; eq[2] = c[2];
+                eq[3] = (double)mn; eq[4] = (double)mx; eq[5] = fabs((double)mx - (double)mn);
+            }
+        }
+        __syncthreads();
+    }
     // find_and_assign_intersections_P: all (row, col) pairs
     const int *rect = S.rect;
     for (int p = t; p < nr * nc; p += 256) {
@@ -405,11 +570,12 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
 }  // namespace
 
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, int h, int w, const int *joints,
-                FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, hipStream_t s)
+                FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
+                int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s)
 {
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
-                       o_id, o_n, o_center);
+                       o_id, o_n, o_center, gray, subpixel, sp_window, sp_step, sp_scratch, sp_cap);
     CPE_CHECK_LAUNCH("k_lines");
     return CPE_OK;
 }

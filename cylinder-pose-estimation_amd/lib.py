@@ -32,6 +32,8 @@ _SIGS = {
     'cpe_detect_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'cpe_detect_grid_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t] +
                               [C.c_void_p] * 6),
+    'cpe_detect_grid_batch_ex': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t] +
+                                 [C.c_void_p] * 6),
     'cpe_detect_workspace_plane': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_debug_ccl': (C.c_int32, [C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     'cpe_fit_workspace_bytes': (C.c_size_t, [C.c_int32]),
@@ -40,6 +42,10 @@ _SIGS = {
     'cpe_fit_cylinder_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p] +
                                [C.c_void_p] * 7),
 }
+
+
+class CpeDetectParams(C.Structure):
+    _fields_ = [('subpixel', C.c_int32), ('subpixel_window', C.c_int32), ('subpixel_step', C.c_double)]
 
 
 class CpeFitParams(C.Structure):

@@ -52,6 +52,8 @@ extern "C" {
 #define CPE_ST_EMPTY 4       /* make_json raises on empty point list, :1703-1704 */
 #define CPE_ST_FEW_POINTS 5  /* too few 3-D points for the fit (fitCylinderWPts3.m:8, estCurvatures.m:5) */
 #define CPE_ST_OVERFLOW 6    /* a fixed capacity of the workspace was exceeded (build-defined) */
+#define CPE_ST_SUBPIXEL_RAISED 7 /* optional sub-pixel stage: a line sample leaves the image through the top / left edge;
+                                   compute_center_of_gravity_x/y raise there (util_cylinder.py:722,741,769,786) */
 
 CPE_API int32_t cpe_version(void);
 CPE_API const char *cpe_last_error_string(void);
@@ -88,6 +90,19 @@ CPE_API size_t cpe_detect_workspace_bytes(int32_t n, int32_t h, int32_t w);
 CPE_API int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t h, int32_t w, void *ws, size_t ws_bytes,
                                       double *xy, int32_t *id, int32_t *n_pts, double *center, int32_t *status,
                                       void *stream);
+
+/* The same with options.  subpixel != 0 inserts the reference's (disabled) grey-level centre-of-gravity refinement
+ * of the fitted lines -- modify_grayscale_Cline(img, rows, cols, degree=2, sample_step, window_size), whose call is
+ * commented out at util_cylinder.py:2040 -- between remove_label and the intersection step.  params NULL = defaults
+ * = the live reference path (subpixel 0). */
+typedef struct CpeDetectParams {
+    int32_t subpixel;        /* 0 = off (reference behaviour) */
+    int32_t subpixel_window; /* window_size (the commented call uses 7) */
+    double subpixel_step;    /* sample_step (1.0) */
+} CpeDetectParams;
+CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
+                                         void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
+                                         double *center, int32_t *status, void *stream);
 
 /* Where an intermediate of the last cpe_detect_grid_batch call lives inside the workspace (for
  * stage-by-stage parity tests and debugging): plane-major, frame f at offset + f * bytes_per_frame. */

@@ -33,6 +33,7 @@ void orc_fit_lines(orc_lineset *ls, int is_row);
 void orc_remove_label(orc_lineset *rows, orc_lineset *cols);
 void orc_intersections(orc_lineset *rows, orc_lineset *cols, const int *rect);
 void orc_clean_and_relabel(orc_lineset *rows, orc_lineset *cols);
+int orc_subpixel_refine(const uint8_t *gray, int h, int w, orc_lineset *rows, orc_lineset *cols, int window, double step);
 int orc_index_points(const orc_lineset *rows, const orc_lineset *cols, const uint8_t *gauss7, int h, int w, int r0,
                      double *center, double *xy, int *id, int cap);
 
@@ -51,8 +52,18 @@ typedef struct {
 } orc_detect_debug;
 
 /* returns status: 0 ok, 1 no region, 2 no spot, 3 no rows/cols, 4 empty */
+ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, int sp_window, double sp_step, double *center,
+                               double *xy, int *id, int cap, int *n_out, orc_detect_debug *dbg);
+
 ORC_API int orc_detect_grid(const uint8_t *gray, int h, int w, double *center, double *xy, int *id, int cap,
                             int *n_out, orc_detect_debug *dbg)
+{
+    return orc_detect_grid_ex(gray, h, w, 0, 7, 1.0, center, xy, id, cap, n_out, dbg);
+}
+
+/* subpixel != 0: modify_grayscale_Cline between remove_label and the intersections (the call commented out at :2040) */
+ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, int sp_window, double sp_step, double *center,
+                               double *xy, int *id, int cap, int *n_out, orc_detect_debug *dbg)
 {
     size_t N = (size_t)h * w;
     uint8_t *blurred = (uint8_t *)malloc(N), *binary = (uint8_t *)malloc(N);
@@ -104,12 +115,15 @@ ORC_API int orc_detect_grid(const uint8_t *gray, int h, int w, double *center, d
         orc_fit_lines(cols, 0);
         orc_fit_lines(rows, 1);
         orc_remove_label(rows, cols);
-        orc_intersections(rows, cols, rect);
-        orc_clean_and_relabel(rows, cols);
-        orc_blur7(gray, h, w, g7);
-        int n = orc_index_points(rows, cols, g7, h, w, r0, center, xy, id, cap);
-        if (n < 0) st = -n;
-        else *n_out = n;
+        if (subpixel) st = orc_subpixel_refine(gray, h, w, rows, cols, sp_window, sp_step);
+        if (st == 0) {
+            orc_intersections(rows, cols, rect);
+            orc_clean_and_relabel(rows, cols);
+            orc_blur7(gray, h, w, g7);
+            int n = orc_index_points(rows, cols, g7, h, w, r0, center, xy, id, cap);
+            if (n < 0) st = -n;
+            else *n_out = n;
+        }
     }
     if (dbg) {
         if (dbg->binary) memcpy(dbg->binary, binary, N);
@@ -126,8 +140,8 @@ ORC_API int orc_detect_grid(const uint8_t *gray, int h, int w, double *center, d
         memcpy(dbg->rect, rect, sizeof(rect));
         dbg->r0 = r0;
         memcpy(dbg->spot, spot, sizeof(spot));
-        dbg->n_rows = (st == 0 || st >= 3) ? rows->nlines : 0;
-        dbg->n_cols = (st == 0 || st >= 3) ? cols->nlines : 0;
+        dbg->n_rows = (st == 0 || (st >= 3 && st != 7)) ? rows->nlines : 0;
+        dbg->n_cols = (st == 0 || (st >= 3 && st != 7)) ? cols->nlines : 0;
         dbg->n_keypoints = nkp;
     }
     free(blurred); free(binary); free(hmask); free(vmask); free(mc); free(roi_h); free(roi_v); free(exp_h); free(exp_v);

@@ -357,3 +357,164 @@ ORC_API int orc_index_points(const orc_lineset *rows, const orc_lineset *cols, c
     }
     return total > cap ? cap : n;
 }
+
+/* ------------------------------------------------------------------------------------------------------
+ * Row f-4: grey-level centre-of-gravity refinement of the fitted lines
+ *   modify_grayscale_Cline / process_row / process_col / compute_center_of_gravity_x,y
+ *   (util_cylinder.py:706-971; its call in color_and_expand_lines is commented out, :2040).
+ * cv2-free for 2-D input: PINNED by tests/golden/subpixel.npz produced by the real functions.
+ * numpy details restated: np.arange(start, stop, step) values are start + i*((start+step)-start);
+ * np.sum of <= 8 float32 / float64 values (sequential below 8, the 8-way tree at 8); refined points are
+ * stored as float32; np.polyfit runs in float64 on those (streaming Givens QR on the column-scaled rows here).
+ * Returns 0, or 7 when the reference raises (a sample lies more than window/2 + 1 px above / left of the image:
+ * negative slice stop at :722,:769 -> shape mismatch at :741,:786).
+ */
+static float sum_f32_np(const float *a, int n)
+{
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    float r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+static double sum_f64_np(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+/* centre of gravity along one axis; along_y: column ix fixed, window over rows.  returns 1 if the reference raises */
+static int cog_refine(const uint8_t *gray, int h, int w, int half, int along_y, double fixed, double moving, double *out)
+{
+    const int L = along_y ? h : w, Lf = along_y ? w : h;
+    int ifx = (int)lrint(fixed); /* int(round(.)): half to even */
+    int lo = (int)floor(moving) - half, hi = (int)ceil(moving) + half + 1;
+    if (lo < 0) lo = 0;
+    if (hi > L) hi = L;
+    *out = moving;
+    if (ifx < 0 || ifx >= Lf) return 0;
+    if (hi < 0) { /* python slice a[lo:hi] with negative hi wraps; np.arange(lo, hi) is empty */
+        int wrapped = L + hi;
+        int len_roi = wrapped > lo ? wrapped - lo : 0;
+        if (len_roi != 0) return 1; /* ValueError: operands could not be broadcast */
+        return 0;                   /* both empty: s == 0 -> unrefined */
+    }
+    int n = hi > lo ? hi - lo : 0;
+    if (n == 0) return 0;
+    float G[16];
+    double prod[16];
+    if (n > 16) n = 16;
+    for (int k = 0; k < n; k++) {
+        int idx = lo + k;
+        uint8_t v = along_y ? gray[(size_t)idx * w + ifx] : gray[(size_t)ifx * w + idx];
+        G[k] = (float)((double)v * (1.0 / 255));
+    }
+    float s = sum_f32_np(G, n);
+    if (s == 0) return 0;
+    for (int k = 0; k < n; k++) prod[k] = (double)(lo + k) * (double)G[k];
+    double cog = sum_f64_np(prod, n) / (double)s;
+    double delta = cog - moving;
+    if (fabs(delta) > 0.5) delta = delta > 0 ? 0.5 : -0.5;
+    double nv = moving + delta;
+    if (nv < 0) nv = 0;
+    if (nv > L - 1) nv = L - 1;
+    *out = nv;
+    return 0;
+}
+
+/* np.polyfit(x, y, 2) in streaming form: column norms, then Givens rotations of the scaled rows into R | c */
+static void polyfit2_stream(const float *xs, const float *ys, int n, double *coef)
+{
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int i = 0; i < n; i++) {
+        double x = (double)xs[i], x2 = x * x;
+        s0 += x2 * x2; s1 += x * x; s2 += 1.0;
+    }
+    double sc[3] = {sqrt(s0), sqrt(s1), sqrt(s2)};
+    double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, c[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        double x = (double)xs[i];
+        double row[3] = {(x * x) / sc[0], x / sc[1], 1.0 / sc[2]}, rhs = (double)ys[i];
+        for (int k = 0; k < 3; k++) {
+            if (row[k] == 0) continue;
+            double a = R[k][k], b = row[k];
+            double r = sqrt(a * a + b * b);
+            double cg = a / r, sg = b / r;
+            for (int j = k; j < 3; j++) {
+                double t = cg * R[k][j] + sg * row[j];
+                row[j] = -sg * R[k][j] + cg * row[j];
+                R[k][j] = t;
+            }
+            double t = cg * c[k] + sg * rhs;
+            rhs = -sg * c[k] + cg * rhs;
+            c[k] = t;
+        }
+    }
+    double z[3];
+    for (int r = 2; r >= 0; r--) {
+        double s = c[r];
+        for (int k = r + 1; k < 3; k++) s -= R[r][k] * z[k];
+        z[r] = s / R[r][r];
+    }
+    for (int k = 0; k < 3; k++) coef[k] = z[k] / sc[k];
+}
+
+/* modify_grayscale_Cline(gray2d, rows, cols, draw_points=False, degree=2, sample_step, window_size) */
+ORC_API int orc_subpixel_refine(const uint8_t *gray, int h, int w, orc_lineset *rows, orc_lineset *cols, int window,
+                                double step)
+{
+    const int half = window / 2;
+    for (int side = 0; side < 2; side++) {
+        orc_lineset *ls = side == 0 ? rows : cols;
+        for (int g = 0; g < ls->nlines; g++) {
+            double *eq = ls->eq[g];
+            double lo = eq[3], hi = eq[4];
+            if (hi < lo) continue;
+            double stop = hi + 0.0001;
+            double cnt = ceil((stop - lo) / step);
+            int K = cnt > 0 ? (int)cnt : 0;
+            if (K == 0) continue;
+            float *xs = (float *)malloc((size_t)K * sizeof(float)), *ys = (float *)malloc((size_t)K * sizeof(float));
+            double delta = (lo + step) - lo;
+            for (int i = 0; i < K; i++) {
+                double t = i == 0 ? lo : (i == 1 ? lo + step : lo + i * delta);
+                double u = ((0.0 * t + eq[0]) * t + eq[1]) * t + eq[2];
+                double ref;
+                int raised = cog_refine(gray, h, w, half, side == 0 ? 1 : 0, t, u, &ref);   /* fixed = sample abscissa, moving = polynomial value */
+                if (raised) { free(xs); free(ys); return 7; }
+                /* rows: (x = t, y = refined); cols: (x = refined, y = t); the polyfit abscissa is t in both */
+                xs[i] = (float)t;
+                ys[i] = (float)ref;
+            }
+            if (K >= 3) {
+                double c[3];
+                polyfit2_stream(xs, ys, K, c);
+                float mn = xs[0], mx = xs[0];
+                for (int i = 1; i < K; i++) { if (xs[i] < mn) mn = xs[i]; if (xs[i] > mx) mx = xs[i]; }
+                eq[0] = c[0]; eq[1] = c[1]; eq[2] = c[2];
+                eq[3] = (double)mn; eq[4] = (double)mx; eq[5] = fabs((double)mx - (double)mn);
+            }
+            free(xs); free(ys);
+        }
+    }
+    return 0;
+}

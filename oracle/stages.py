@@ -231,7 +231,7 @@ class DetectDebug(C.Structure):
                 ('n_keypoints', C.c_int)]
 
 
-def detect_grid(gray, cap=4096, debug=False):
+def detect_grid(gray, cap=4096, debug=False, subpixel=False, window=7, step=1.0):
     """detect_grid restated: -> dict(status, center (2,), xy (n,2), id (n,2) [, debug images])"""
     gray = _u8(gray); h, w = gray.shape
     center = np.zeros(2); xy = np.zeros((cap, 2)); ids = np.zeros((cap, 2), np.int32); n = C.c_int(0)
@@ -242,8 +242,8 @@ def detect_grid(gray, cap=4096, debug=False):
             setattr(dbg, k, imgs[k].ctypes.data)
         imgs['joints'] = np.zeros((1 << 16, 2), np.int32)
         dbg.joints = imgs['joints'].ctypes.data; dbg.cap_joints = 1 << 16
-    st = lib().orc_detect_grid(_p(gray, C.c_uint8), h, w, _p(center, C.c_double), _p(xy, C.c_double), _p(ids, C.c_int),
-                               cap, C.byref(n), C.byref(dbg))
+    st = lib().orc_detect_grid_ex(_p(gray, C.c_uint8), h, w, 1 if subpixel else 0, window, C.c_double(step),
+                                  _p(center, C.c_double), _p(xy, C.c_double), _p(ids, C.c_int), cap, C.byref(n), C.byref(dbg))
     out = dict(status=st, center=center, xy=xy[:n.value].copy(), id=ids[:n.value].copy(), rect=tuple(dbg.rect),
                r0=dbg.r0, spot=tuple(dbg.spot), n_joints=dbg.n_joints, n_cyl_joints=dbg.n_cyl_joints,
                n_rows=dbg.n_rows, n_cols=dbg.n_cols, n_keypoints=dbg.n_keypoints)
@@ -251,3 +251,18 @@ def detect_grid(gray, cap=4096, debug=False):
         imgs['joints'] = imgs['joints'][:dbg.n_joints].copy()
         out.update(imgs)
     return out
+
+
+def lineset_from_equations(eqs):
+    """LineSet carrying only equations (for the sub-pixel refinement tests)"""
+    ls = LineSet(); ls.nlines = len(eqs)
+    for g, e in enumerate(eqs):
+        for k in range(6):
+            ls.eq[g][k] = float(e[k])
+    return ls
+
+
+def subpixel_refine(gray, rows, cols, window=7, step=1.0):
+    """modify_grayscale_Cline(gray2d, rows, cols, draw_points=False, degree=2, step, window): status 0 or 7 (raises)"""
+    gray = _u8(gray); h, w = gray.shape
+    return lib().orc_subpixel_refine(_p(gray, C.c_uint8), h, w, C.byref(rows), C.byref(cols), window, C.c_double(step))

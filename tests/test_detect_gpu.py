@@ -140,3 +140,28 @@ def test_pipeline_records_and_profile(cpe, orc, gpu):
             assert np.array_equal(r1[i, :12].cpu().numpy(), ref['cyl'].ravel())
             assert np.array_equal(r1[i, 12:14].cpu().numpy(), ref['fvals'])
             assert int(n_pts[i]) == len(ref['pts3']) and int(iters[i]) == ref['iters']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w,seed', [(480, 640, 0), (1200, 1920, 13)])
+def test_subpixel_mode_matches_oracle(cpe, orc, gpu, h, w, seed):
+    """optional stage f-4 (modify_grayscale_Cline, disabled in the reference's live path): GPU == oracle, bit for bit,
+    including the frames on which the reference's code raises (status 7)"""
+    from oracle import stages as S
+    frames = _frames(h, w, 2, seed)
+    det = cpe.api.detect_grid_batch(frames.to(gpu), subpixel=True)
+    torch.cuda.synchronize()
+    n_ok = 0
+    for i in range(frames.shape[0]):
+        ref = S.detect_grid(frames[i].numpy(), subpixel=True)
+        assert int(det['status'][i]) == ref['status'], i
+        if ref['status'] != 0:
+            continue
+        n_ok += 1
+        m = int(det['n'][i])
+        assert m == len(ref['xy'])
+        assert np.array_equal(det['id'][i, :m].cpu().numpy(), ref['id'])
+        assert np.array_equal(det['xy'][i, :m].cpu().numpy(), ref['xy']), np.abs(det['xy'][i, :m].cpu().numpy() - ref['xy']).max()
+        base = S.detect_grid(frames[i].numpy())
+        assert not np.array_equal(base['xy'], ref['xy'])                  # the stage does move the points
+    assert n_ok >= 2

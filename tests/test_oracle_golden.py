@@ -93,3 +93,24 @@ def test_pca_endpoints_vs_numpy_lapack(orc):
     for c in d['cases']:
         p1, p2 = S.pca_endpoints(c['pts'])
         assert list(map(float, p1)) == c['p1'] and list(map(float, p2)) == c['p2']
+
+
+def test_subpixel_refinement_vs_reference(orc):
+    """modify_grayscale_Cline (real function, 2-D grey input, draw_points=False) vs the oracle restatement:
+    refitted equations within 1e-9 relative (coefficients of magnitude >= 1e-6; 1e-12 absolute below), domains equal;
+    and the case in which the reference raises is reported as status 7."""
+    from oracle import stages as S
+    z = np.load(os.path.join(GOLDEN, 'subpixel.npz'))
+    spec = json.loads(str(z['spec'])); gray = z['gray']
+    rk, ck = list(spec['rows_in']), list(spec['cols_in'])
+    rows = S.lineset_from_equations([spec['rows_in'][k] for k in rk])
+    cols = S.lineset_from_equations([spec['cols_in'][k] for k in ck])
+    assert S.subpixel_refine(gray, rows, cols, spec['window'], spec['step']) == 0
+    for ls, keys, out in ((rows, rk, spec['rows_out']), (cols, ck, spec['cols_out'])):
+        for g, k in enumerate(keys):
+            got, want = np.array(ls.equations()[g]), np.array(out[k])
+            np.testing.assert_allclose(got[:3], want[:3], rtol=1e-9, atol=1e-12)
+            assert np.array_equal(got[3:], want[3:]), k                     # float32-rounded domain, bit for bit
+    assert spec['bad_row_raises']
+    bad = S.lineset_from_equations([spec['bad_row']]); none = S.lineset_from_equations([])
+    assert S.subpixel_refine(gray, bad, none, spec['window'], spec['step']) == 7

@@ -192,3 +192,55 @@ if __name__ == '__main__':
     gen_json()
     gen_pca()
     print('golden vectors written to', os.path.abspath(OUT))
+
+
+def gen_subpixel():
+    """modify_grayscale_Cline (util_cylinder.py:907-971; dead in the live path, call commented at :2040) on a 2-D
+    grey image with draw_points=False -- cv2-free, so the REAL function runs: rows y=f(x) are re-fitted after a
+    grey-level centre-of-gravity correction of y (compute_center_of_gravity_y :706-751), cols likewise in x."""
+    h, w = 200, 260
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = 10 + 2 * rng.standard_normal((h, w))
+    row_defs, col_defs = [], []
+    for k in range(5):
+        a2, a1, a0 = 0.00008 * (k - 2), 0.03 * (k - 2) + 0.01, 31 + 33.5 * k
+        img += 180 * np.exp(-0.5 * ((yy - (a2 * xx ** 2 + a1 * xx + a0)) / 1.6) ** 2)
+        row_defs.append((a2, a1, a0))
+    for k in range(6):
+        b2, b1, b0 = -0.0001 * (k - 2), 0.02 * (k - 3), 26 + 40.25 * k
+        img += 170 * np.exp(-0.5 * ((xx - (b2 * yy ** 2 + b1 * yy + b0)) / 1.5) ** 2)
+        col_defs.append((b2, b1, b0))
+    gray = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    rows = {"points": {}, "equations": {}}
+    cols = {"points": {}, "equations": {}}
+    for i, (a2, a1, a0) in enumerate(row_defs, 1):     # start equations: the true lines, perturbed by a fraction of a pixel
+        x0, x1 = float(rng.uniform(-30, 20)), float(rng.uniform(w - 30, w + 40))
+        rows["equations"][f"col{i}"] = [a2 * (1 + 0.02 * rng.standard_normal()), a1 + 1e-3 * rng.standard_normal(),
+                                        a0 + rng.uniform(-0.8, 0.8), x0, x1, abs(x1 - x0)]
+        rows["points"][f"col{i}"] = []
+    for i, (b2, b1, b0) in enumerate(col_defs, 1):
+        y0, y1 = float(rng.uniform(-25, 15)), float(rng.uniform(h - 20, h + 30))
+        cols["equations"][f"col{i}"] = [b2 * (1 + 0.02 * rng.standard_normal()), b1 + 1e-3 * rng.standard_normal(),
+                                        b0 + rng.uniform(-0.8, 0.8), y0, y1, abs(y1 - y0)]
+        cols["points"][f"col{i}"] = []
+    rows["equations"]["col6"] = [0, 0, 0, 0, 0, 0]; rows["points"]["col6"] = []       # a dummy [0]*6 equation
+    _, r2, c2 = uc.modify_grayscale_Cline(gray, rows, cols, draw_points=False, degree=2, sample_step=1.0, window_size=7)
+    # a row that leaves the image through the top edge: the reference raises (negative slice stop, :721-741)
+    bad = {"points": {"col1": []}, "equations": {"col1": [0.0, -0.2, 20.0, 0.0, 250.0, 250.0]}}
+    raised = False
+    try:
+        uc.modify_grayscale_Cline(gray, bad, {"points": {}, "equations": {}}, draw_points=False, degree=2, sample_step=1.0, window_size=7)
+    except ValueError:
+        raised = True
+    out = dict(meta=META, h=h, w=w, window=7, step=1.0, bad_row=bad["equations"]["col1"], bad_row_raises=raised,
+               rows_in={k: [float(x) for x in v] for k, v in rows["equations"].items()},
+               cols_in={k: [float(x) for x in v] for k, v in cols["equations"].items()},
+               rows_out={k: [float(x) for x in v] for k, v in r2["equations"].items()},
+               cols_out={k: [float(x) for x in v] for k, v in c2["equations"].items()})
+    np.savez_compressed(os.path.join(OUT, 'subpixel.npz'), gray=gray, spec=json.dumps(out))
+
+
+if __name__ == '__main__':
+    gen_subpixel()
+    print('subpixel golden written')
