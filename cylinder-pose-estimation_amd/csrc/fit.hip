@@ -949,3 +949,50 @@ extern "C" int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, i
     CPE_CHECK_LAUNCH("k_fit_cylinder");
     return CPE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row f-1: objective of the multi-frame AGV-pose fit, utils/fitCylinderWPts3sAngs.m:82-94 (`dist`):
+//   v = sum_i mean((d_i - R)^2),  d_i = getDistPts3ToLine(Pts3s{i}, line of T * TAGVcyls{i})
+// One wavefront per frame computes its term (same 64-lane reduction tree as the per-frame fit); the host-side
+// Nelder-Mead (cpe_amd/multiframe.py, MATLAB fminsearch order) adds the F terms in frame order.
+namespace {
+__global__ __launch_bounds__(64) void k_multi_frame_terms(const double *__restrict__ X, const int *__restrict__ cnt,
+                                                          const double *__restrict__ TAGV, const double *__restrict__ T,
+                                                          double R, double *__restrict__ terms)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = min(max(cnt[f], 0), MAXP);
+    if (n == 0) { if (lane == 0) terms[f] = 0.0; return; }
+    // T_C1_cyl = T * TAGVcyls{i}: only column 2 (axis) and column 4 (origin) are used
+    const double *A = TAGV + 16 * (size_t)f;
+    double org[3], dy[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        dy[r] = ((T[r * 4] * A[1] + T[r * 4 + 1] * A[5]) + T[r * 4 + 2] * A[9]) + T[r * 4 + 3] * A[13];
+        org[r] = ((T[r * 4] * A[3] + T[r * 4 + 1] * A[7]) + T[r * 4 + 2] * A[11]) + T[r * 4 + 3] * A[15];
+    }
+    double p2[3] = {org[0] + dy[0], org[1] + dy[1], org[2] + dy[2]};
+    double v[3] = {p2[0] - org[0], p2[1] - org[1], p2[2] - org[2]};
+    double nv2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    const double *P = X + (size_t)f * MAXP * 3;
+    double acc = 0.0;
+    for (int k = lane; k < n; k += 64) {
+        double d = dist_pt_line(P + 3 * k, org, v, nv2);
+        double w = d - R;
+        acc = acc + w * w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) terms[f] = acc / (double)n;
+}
+}  // namespace
+
+extern "C" int32_t cpe_multi_frame_terms(const double *X, const int32_t *cnt, int32_t n, const double *TAGVcyl,
+                                         const double *T, double radius, double *terms, void *stream)
+{
+    CPE_CHECK_ARG(X && cnt && TAGVcyl && T && terms && n >= 0, "cpe_multi_frame_terms: bad argument");
+    if (n == 0) return CPE_OK;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_multi_frame_terms, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, TAGVcyl, T, radius, terms);
+    CPE_CHECK_LAUNCH("k_multi_frame_terms");
+    return CPE_OK;
+}

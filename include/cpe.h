@@ -187,6 +187,13 @@ CPE_API int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, int3
                                        const CpeFitParams *params, double *cyl_raw, double *cyl, double *T,
                                        double *fvals, int32_t *iters, int32_t *status, void *stream);
 
+/* Row f-1: the per-frame terms of the multi-frame objective of fitCylinderWPts3sAngs.m:82-94 (`dist`):
+ * terms[i] = mean((getDistPts3ToLine(Pts3s{i}, line(T * TAGVcyls{i})) - radius)^2), one wavefront per frame.
+ * X f64[n,CPE_MAXP,3], cnt i32[n], TAGVcyl f64[n,16] (row-major getTAGVcyl(pan,tilt)), T f64[16] (device, row-major
+ * vec2T(agvPose)).  The 6-parameter Nelder-Mead around it runs on the host (cpe_amd/multiframe.py). */
+CPE_API int32_t cpe_multi_frame_terms(const double *X, const int32_t *cnt, int32_t n, const double *TAGVcyl,
+                                      const double *T, double radius, double *terms, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,3 +169,37 @@ def fit_single_cylinder(gp1, gp2, K1, K2, T21, R, selector=0, th=0.3):
                                        C.byref(it), C.byref(ev), C.byref(fb))
     return dict(pts3=pts3[:m.value].copy(), cyl=cyl, T=T, fvals=fv, mean_err=me.value, iters=it.value,
                 evals=ev.value, status=st, fallback=bool(fb.value))
+
+
+# ---------------------------------------------------------------- row f-1: multi-frame AGV-pose fit
+def get_TAGVcyl(pan, tilt):
+    T = np.empty(16)
+    lib().orc_get_TAGVcyl(C.c_double(pan), C.c_double(tilt), _p(T, C.c_double))
+    return T
+
+
+def vec2T(x):
+    x = _f64(x); T = np.empty(16)
+    lib().orc_vec2T(_p(x, C.c_double), _p(T, C.c_double)); return T
+
+
+def T2vec(T):
+    T = _f64(T).ravel(); x = np.empty(6)
+    lib().orc_T2vec(_p(T, C.c_double), _p(x, C.c_double)); return x
+
+
+def multi_objective(x, P, cnt, TAGV, R):
+    x = _f64(x); P = _f64(P); cnt = np.ascontiguousarray(cnt, np.int32); TAGV = _f64(TAGV)
+    lib().orc_multi_objective.restype = C.c_double
+    return lib().orc_multi_objective(_p(x, C.c_double), _p(P, C.c_double), _p(cnt, C.c_int), len(cnt), P.shape[1],
+                                     _p(TAGV, C.c_double), C.c_double(R))
+
+
+def multi_fit(P, cnt, TAGV, cyl_raw, R):
+    """fitCylinderWPts3sAngs: P (F,cap,3), cnt (F,), TAGV (F,16), cyl_raw (F,2,6) -> dict(x0, x, T, fvals, iters, evals)"""
+    P = _f64(P); cnt = np.ascontiguousarray(cnt, np.int32); TAGV = _f64(TAGV); cyl_raw = _f64(cyl_raw)
+    x0 = np.empty(6); x = np.empty(6); T = np.empty(16); fv = np.empty(2); it = C.c_int(0); ev = C.c_int(0)
+    lib().orc_multi_fit(_p(P, C.c_double), _p(cnt, C.c_int), len(cnt), P.shape[1], _p(TAGV, C.c_double),
+                        _p(cyl_raw, C.c_double), C.c_double(R), _p(x0, C.c_double), _p(x, C.c_double), _p(T, C.c_double),
+                        _p(fv, C.c_double), C.byref(it), C.byref(ev))
+    return dict(x0=x0, x=x, T=T, fvals=fv, iters=it.value, evals=ev.value)

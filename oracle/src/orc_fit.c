@@ -381,19 +381,37 @@ static double eps_of(double x) /* MATLAB eps(x) */
 }
 
 /* fminsearch clone (MATLAB fminsearch.m). n = 6. */
+typedef double (*nm_objective)(const double *x, void *ctx);
+typedef struct { const double *P; int n; double R; double *tmp; } cyl_ctx;
+static double cyl_obj_cb(const double *x, void *c_)
+{
+    cyl_ctx *c = (cyl_ctx *)c_;
+    return cyl_objective(x, c->P, c->n, c->R, c->tmp);
+}
+
+static void nelder_mead6_fn(const double *x0, nm_objective fobj, void *ctx, double tolx, double tolf, int maxiter,
+                            int maxfun, double *xout, double *fout, int *iters, int *evals);
+
 static void nelder_mead6(const double *x0, const double *P, int n, double R, double tolx, double tolf,
                          int maxiter, int maxfun, double *xout, double *fout, int *iters, int *evals)
 {
+    cyl_ctx c = {P, n, R, (double *)malloc((size_t)(n + 1) * sizeof(double))};
+    nelder_mead6_fn(x0, cyl_obj_cb, &c, tolx, tolf, maxiter, maxfun, xout, fout, iters, evals);
+    free(c.tmp);
+}
+
+static void nelder_mead6_fn(const double *x0, nm_objective fobj, void *ctx, double tolx, double tolf, int maxiter,
+                            int maxfun, double *xout, double *fout, int *iters, int *evals)
+{
     enum { N = 6 };
     double v[N + 1][N], fv[N + 1];
-    double *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
     memcpy(v[0], x0, sizeof(double) * N);
-    fv[0] = cyl_objective(v[0], P, n, R, tmp);
+    fv[0] = fobj(v[0], ctx);
     for (int j = 0; j < N; j++) {
         memcpy(v[j + 1], x0, sizeof(double) * N);
         if (v[j + 1][j] != 0) v[j + 1][j] = (1 + 0.05) * v[j + 1][j];
         else v[j + 1][j] = 0.00025;
-        fv[j + 1] = cyl_objective(v[j + 1], P, n, R, tmp);
+        fv[j + 1] = fobj(v[j + 1], ctx);
     }
     int func_evals = N + 1, itercount = 1;
 #define SORT_SIMPLEX()                                                             \
@@ -432,12 +450,12 @@ static void nelder_mead6(const double *x0, const double *P, int n, double R, dou
             xbar[k] = s / N;
         }
         for (int k = 0; k < N; k++) xr[k] = 2.0 * xbar[k] - 1.0 * v[N][k];
-        double fxr = cyl_objective(xr, P, n, R, tmp);
+        double fxr = fobj(xr, ctx);
         func_evals++;
         int shrink = 0;
         if (fxr < fv[0]) {
             for (int k = 0; k < N; k++) xe[k] = 3.0 * xbar[k] - 2.0 * v[N][k];
-            double fxe = cyl_objective(xe, P, n, R, tmp);
+            double fxe = fobj(xe, ctx);
             func_evals++;
             if (fxe < fxr) { memcpy(v[N], xe, sizeof xe); fv[N] = fxe; }
             else { memcpy(v[N], xr, sizeof xr); fv[N] = fxr; }
@@ -445,13 +463,13 @@ static void nelder_mead6(const double *x0, const double *P, int n, double R, dou
             memcpy(v[N], xr, sizeof xr); fv[N] = fxr;
         } else if (fxr < fv[N]) {
             for (int k = 0; k < N; k++) xc[k] = 1.5 * xbar[k] - 0.5 * v[N][k];
-            double fxc = cyl_objective(xc, P, n, R, tmp);
+            double fxc = fobj(xc, ctx);
             func_evals++;
             if (fxc <= fxr) { memcpy(v[N], xc, sizeof xc); fv[N] = fxc; }
             else shrink = 1;
         } else {
             for (int k = 0; k < N; k++) xc[k] = 0.5 * xbar[k] + 0.5 * v[N][k];
-            double fxcc = cyl_objective(xc, P, n, R, tmp);
+            double fxcc = fobj(xc, ctx);
             func_evals++;
             if (fxcc < fv[N]) { memcpy(v[N], xc, sizeof xc); fv[N] = fxcc; }
             else shrink = 1;
@@ -459,7 +477,7 @@ static void nelder_mead6(const double *x0, const double *P, int n, double R, dou
         if (shrink) {
             for (int j = 1; j <= N; j++) {
                 for (int k = 0; k < N; k++) v[j][k] = v[0][k] + 0.5 * (v[j][k] - v[0][k]);
-                fv[j] = cyl_objective(v[j], P, n, R, tmp);
+                fv[j] = fobj(v[j], ctx);
             }
             func_evals += N;
         }
@@ -471,7 +489,6 @@ static void nelder_mead6(const double *x0, const double *P, int n, double R, dou
     *fout = fv[0];
     *iters = itercount;
     *evals = func_evals;
-    free(tmp);
 }
 
 /* Levenberg-Marquardt on the same objective -- restatement of the build's own fast mode (csrc/fit.hip),
@@ -788,4 +805,201 @@ ORC_API int orc_fit_single_cylinder(const double *gp1, int n1, const double *gp2
     }
     free(c1); free(c2);
     return st;
+}
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row f-1: multi-frame AGV-pose fit, utils/fitCylinderWPts3sAngs.m:1-94 (+ getTAGVcyl.m, vec2T.m,
+ * T2vec.m).  [ext] rotvec2mat3d / rotmat2vec3d / mrdivide / fminsearch restated -- PARITY UNPINNED (no MATLAB).
+ * Reproduced quirk: cylParams{i} is the 2x6 matrix [cylParams0; cylParams] and applyCylParamsPrior indexes it
+ * LINEARLY (applyCylParamsPrior.m:6-7), so "origin" = [M(1,1) M(2,1) M(1,2)] and "direction" = [M(2,2) M(1,3) M(2,3)].
+ */
+ORC_API void orc_get_TAGVcyl(double pan, double tilt, double *T) /* getTAGVcyl.m, row-major 4x4 */
+{
+    double cp = cos(pan), sp = sin(pan), ct = cos(-tilt), st = sin(-tilt);
+    double TAP[16] = {cp, -sp, 0, 0, sp, cp, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double TPT0[16] = {1, 0, 0, -143.1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double L = sqrt((-143.1 * -143.1 + 0.0 * 0.0) + 0.0 * 0.0);
+    double mtr = -tan(tilt) * L;
+    double T01[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, mtr, 0, 0, 0, 1};
+    double T12[16] = {ct, 0, st, 0, 0, 1, 0, 0, -st, 0, ct, 0, 0, 0, 0, 1};
+    double T2C[16] = {0, -1, 0, 321.1, -1, 0, 0, 0, 0, 0, -1, 110, 0, 0, 0, 1};
+    const double *chain[4] = {TPT0, T01, T12, T2C};
+    double acc[16], nxt[16];
+    memcpy(acc, TAP, sizeof acc);
+    for (int m = 0; m < 4; m++) {
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                double s_ = 0.0;
+                for (int k = 0; k < 4; k++) s_ = s_ + acc[r * 4 + k] * chain[m][k * 4 + c];
+                nxt[r * 4 + c] = s_;
+            }
+        memcpy(acc, nxt, sizeof acc);
+    }
+    memcpy(T, acc, sizeof acc);
+}
+
+static void rotvec2mat(const double *v, double *R) /* rotvec2mat3d (premultiply) */
+{
+    double th = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    if (th < 1e-6) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    double u[3] = {v[0] / th, v[1] / th, v[2] / th};
+    double c = cos(th), s_ = sin(th), t = 1 - c;
+    double K[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 3; q++) R[r * 3 + q] = (c * (r == q ? 1.0 : 0.0) + t * (u[r] * u[q])) + s_ * K[r * 3 + q];
+}
+static void mat2rotvec(const double *R, double *v) /* rotmat2vec3d (without its SVD re-orthogonalisation) */
+{
+    double t = (R[0] + R[4]) + R[8];
+    double ca = (t - 1) / 2;
+    if (ca > 1) ca = 1;
+    if (ca < -1) ca = -1;
+    double th = acos(ca);
+    double r[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    if (sin(th) >= 1e-4) {
+        double vth = 1 / (2 * sin(th));
+        for (int k = 0; k < 3; k++) v[k] = th * (r[k] * vth);
+    } else if (t - 1 > 0) {
+        for (int k = 0; k < 3; k++) v[k] = (.5 - (t - 3) / 12) * r[k];
+    } else {
+        int a = 0;
+        if (R[4] > R[a * 4]) a = 1;
+        if (R[8] > R[a * 4]) a = 2;
+        int b = (a + 1) % 3, c = (a + 2) % 3;
+        double s_ = sqrt(R[a * 4] - R[b * 4] - R[c * 4] + 1);
+        double w[3];
+        w[a] = s_ / 2;
+        w[b] = (R[b * 3 + a] + R[a * 3 + b]) / (2 * s_);
+        w[c] = (R[c * 3 + a] + R[a * 3 + c]) / (2 * s_);
+        double nw = sqrt((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+        for (int k = 0; k < 3; k++) v[k] = th * w[k] / nw;
+    }
+}
+ORC_API void orc_vec2T(const double *x, double *T) /* vec2T.m, row-major */
+{
+    double R[9];
+    rotvec2mat(x, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[r * 4 + c] = R[r * 3 + c]; T[r * 4 + 3] = x[3 + r]; }
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+ORC_API void orc_T2vec(const double *T, double *x) /* T2vec.m */
+{
+    double R[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[r * 3 + c] = T[r * 4 + c];
+    mat2rotvec(R, x);
+    for (int r = 0; r < 3; r++) x[3 + r] = T[r * 4 + 3];
+}
+
+typedef struct { const double *P; const int *cnt; int F, cap; const double *TAGV; double R; double *tmp; } multi_ctx;
+/* dist() of fitCylinderWPts3sAngs.m:82-94 */
+static double multi_obj(const double *x, void *c_)
+{
+    multi_ctx *c = (multi_ctx *)c_;
+    double T[16];
+    orc_vec2T(x, T);
+    double v = 0;
+    for (int i = 0; i < c->F; i++) {
+        const double *A = c->TAGV + 16 * (size_t)i;
+        int n = c->cnt[i];
+        if (n <= 0) { v = v + 0.0; continue; }
+        double org[3], dy[3];
+        for (int r = 0; r < 3; r++) {
+            dy[r] = ((T[r * 4] * A[1] + T[r * 4 + 1] * A[5]) + T[r * 4 + 2] * A[9]) + T[r * 4 + 3] * A[13];
+            org[r] = ((T[r * 4] * A[3] + T[r * 4 + 1] * A[7]) + T[r * 4 + 2] * A[11]) + T[r * 4 + 3] * A[15];
+        }
+        double p2[3] = {org[0] + dy[0], org[1] + dy[1], org[2] + dy[2]};
+        dist_to_line(c->P + (size_t)i * c->cap * 3, n, org, p2, c->tmp);
+        for (int k = 0; k < n; k++) { double w = c->tmp[k] - c->R; c->tmp[k] = w * w; }
+        v = v + sum64(c->tmp, n) / n;
+    }
+    return v;
+}
+
+ORC_API double orc_multi_objective(const double *x, const double *P, const int *cnt, int F, int cap, const double *TAGV, double R)
+{
+    multi_ctx c = {P, cnt, F, cap, TAGV, R, (double *)malloc((size_t)(cap + 1) * sizeof(double))};
+    double v = multi_obj(x, &c);
+    free(c.tmp);
+    return v;
+}
+
+static void cross3v(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* initial AGV pose T0 of fitCylinderWPts3sAngs.m:40-69 from the (quirkily indexed) per-frame fits */
+ORC_API void orc_multi_init(const double *cyl_raw /* F x 2 x 6 */, const double *P, const int *cnt, int cap,
+                            const double *TAGV, double *x0)
+{
+    double cp[2][6];
+    for (int i = 0; i < 2; i++) {
+        const double *M = cyl_raw + 12 * (size_t)i; /* M(r,c) = M[r*6 + c]; linear index k (1-based): row (k-1)%2, col (k-1)/2 */
+        double lin[6];
+        for (int k = 0; k < 6; k++) lin[k] = M[(k % 2) * 6 + (k / 2)];
+        memcpy(cp[i], lin, sizeof lin);
+        orc_apply_prior(cp[i], P + (size_t)i * cap * 3, cnt[i]);
+    }
+    const double *A1 = TAGV, *A2 = TAGV + 16;
+    double p1[3] = {A1[3], A1[7], A1[11]}, p2[3] = {A2[3], A2[7], A2[11]};
+    double y1[3] = {A1[1], A1[5], A1[9]};
+    double d12[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    double nd[3]; cross3v(y1, d12, nd);
+    double nn = sqrt((nd[0] * nd[0] + nd[1] * nd[1]) + nd[2] * nd[2]);
+    for (int k = 0; k < 3; k++) nd[k] = nd[k] / nn;
+    double ed12[3] = {cp[1][0] - cp[0][0], cp[1][1] - cp[0][1], cp[1][2] - cp[0][2]};
+    double dir1[3] = {cp[0][3], cp[0][4], cp[0][5]};
+    double en[3]; cross3v(dir1, ed12, en);
+    double ne = sqrt((en[0] * en[0] + en[1] * en[1]) + en[2] * en[2]);
+    for (int k = 0; k < 3; k++) en[k] = en[k] / ne;
+    double c1[3], c2[3];
+    cross3v(dir1, en, c1);
+    cross3v(y1, nd, c2);
+    /* R = A / B with A = [dir1 en c1], B = [y1 nd c2] (columns): solve R B = A  <=>  B' R' = A' by Gaussian elimination */
+    double Bt[9], At[9];
+    const double *Ac[3] = {dir1, en, c1}, *Bc[3] = {y1, nd, c2};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { Bt[r * 3 + c] = Bc[r][c]; At[r * 3 + c] = Ac[r][c]; }
+    for (int c = 0; c < 3; c++) {
+        int pv = c;
+        for (int r = c + 1; r < 3; r++) if (fabs(Bt[r * 3 + c]) > fabs(Bt[pv * 3 + c])) pv = r;
+        if (pv != c) for (int k = 0; k < 3; k++) {
+            double t_ = Bt[c * 3 + k]; Bt[c * 3 + k] = Bt[pv * 3 + k]; Bt[pv * 3 + k] = t_;
+            t_ = At[c * 3 + k]; At[c * 3 + k] = At[pv * 3 + k]; At[pv * 3 + k] = t_;
+        }
+        for (int r = c + 1; r < 3; r++) {
+            double f = Bt[r * 3 + c] / Bt[c * 3 + c];
+            for (int k = c; k < 3; k++) Bt[r * 3 + k] = Bt[r * 3 + k] - f * Bt[c * 3 + k];
+            for (int k = 0; k < 3; k++) At[r * 3 + k] = At[r * 3 + k] - f * At[c * 3 + k];
+        }
+    }
+    double Rt[9];
+    for (int k = 0; k < 3; k++)
+        for (int r = 2; r >= 0; r--) {
+            double s_ = At[r * 3 + k];
+            for (int q = r + 1; q < 3; q++) s_ = s_ - Bt[r * 3 + q] * Rt[q * 3 + k];
+            Rt[r * 3 + k] = s_ / Bt[r * 3 + r];
+        }
+    double T0[16];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T0[r * 4 + c] = Rt[c * 3 + r];
+    }
+    for (int r = 0; r < 3; r++) {
+        double s_ = (T0[r * 4] * p1[0] + T0[r * 4 + 1] * p1[1]) + T0[r * 4 + 2] * p1[2];
+        T0[r * 4 + 3] = cp[0][r] - s_;
+    }
+    T0[12] = 0; T0[13] = 0; T0[14] = 0; T0[15] = 1;
+    orc_T2vec(T0, x0);
+}
+
+/* fitCylinderWPts3sAngs: P (F x cap x 3), cnt[F], TAGV (F x 16), cyl_raw (F x 2 x 6 from fitCylinderWPts3 per frame) */
+ORC_API void orc_multi_fit(const double *P, const int *cnt, int F, int cap, const double *TAGV, const double *cyl_raw, double R,
+                           double *x0, double *x, double *T, double *fvals, int *iters, int *evals)
+{
+    orc_multi_init(cyl_raw, P, cnt, cap, TAGV, x0);
+    multi_ctx c = {P, cnt, F, cap, TAGV, R, (double *)malloc((size_t)(cap + 1) * sizeof(double))};
+    fvals[0] = multi_obj(x0, &c);
+    nelder_mead6_fn(x0, multi_obj, &c, 1e-5, 1e-5, 100000, 100000, x, &fvals[1], iters, evals);
+    orc_vec2T(x, T);
+    free(c.tmp);
 }
