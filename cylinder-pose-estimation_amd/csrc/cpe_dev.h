@@ -164,6 +164,7 @@ __device__ bool trace_border(const Pred &nz, int x0, int y0, bool is_hole, Visit
         vis.point(x3, y3, vertex);
         if (vertex) prev_s = s;
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return true;
+        if (vis.stop()) return true;   // the visitor has seen enough (e.g. more vertices than its consumer accepts)
         x3 = x4;
         y3 = y4;
         s = (s + 4) & 7;
@@ -220,6 +221,7 @@ struct StatVisitor {
         px = x; py = y;
     }
     __device__ __forceinline__ void finish() { if (have_prev) edge(px, py, fx, fy); }
+    __device__ __forceinline__ bool stop() const { return false; }
 };
 
 // cv2.moments(contour): m00, m10, m01 from the Green sums (contourMoments)

@@ -123,6 +123,68 @@ __global__ __launch_bounds__(256) void k_or_and(const uint8_t *a, const uint8_t 
     if (gi < total) dst[gi] = ((a[gi] ? 255 : 0) | (b[gi] ? 255 : 0)) & c[gi];
 }
 
+// a-5 tail + a-6 head in one kernel:  roi = open3x3(mask & circle_mask & mask_contour)  (util_cylinder.py:1995-2005),
+// base = close3x3(roi) (:150-152).  64x32 tile with a 4-px apron in LDS; out-of-image pixels never erode / dilate.
+constexpr int RT_X = 64, RT_Y = 32, RAP = 4;
+constexpr int RW = RT_X + 2 * RAP, RH = RT_Y + 2 * RAP;
+__global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m, const uint8_t *__restrict__ cm,
+                                                  const uint8_t *__restrict__ mc, int h, int w, int tiles_x, int tiles_y,
+                                                  uint8_t *__restrict__ roi, uint8_t *__restrict__ base)
+{
+    __shared__ uint8_t a[RH * RW], b[RH * RW];   // 0 / 1, 2 = outside the image
+    const int t = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
+    const int gx0 = (tt % tiles_x) * RT_X, gy0 = (tt / tiles_x) * RT_Y;
+    const size_t N = (size_t)h * w;
+    for (int i = t; i < RH * RW; i += 256) {
+        int ry = i / RW, rx = i - ry * RW;
+        int y = gy0 - RAP + ry, x = gx0 - RAP + rx;
+        uint8_t v = 2;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            size_t o = f * N + (size_t)y * w + x;
+            v = ((m[o] & cm[o]) & mc[o]) ? 1 : 0;
+        }
+        a[i] = v;
+    }
+    __syncthreads();
+    // one 3x3 pass src -> dst on the ring [r, R-r): mode 0 erode, 1 dilate
+    auto pass = [&](const uint8_t *src, uint8_t *dst, int r, int dil) {
+        for (int i = t; i < RH * RW; i += 256) {
+            int ry = i / RW, rx = i - ry * RW;
+            uint8_t c = src[i];
+            uint8_t o = c;
+            if (c != 2 && ry >= r && ry < RH - r && rx >= r && rx < RW - r) {
+                bool res = !dil;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        uint8_t q = src[(ry + dy) * RW + rx + dx];
+                        if (q == 2) continue;
+                        if (dil) res = res || (q == 1);
+                        else res = res && (q == 1);
+                    }
+                o = res ? 1 : 0;
+            }
+            dst[i] = o;
+        }
+        __syncthreads();
+    };
+    pass(a, b, 1, 0);   // erode
+    pass(b, a, 2, 1);   // dilate -> roi (valid on ring >= 2)
+    for (int i = t; i < RT_Y * RT_X; i += 256) {
+        int ry = i / RT_X, rx = i - ry * RT_X;
+        int y = gy0 + ry, x = gx0 + rx;
+        if (y < h && x < w) roi[f * N + (size_t)y * w + x] = a[(ry + RAP) * RW + rx + RAP] == 1 ? 255 : 0;
+    }
+    pass(a, b, 3, 1);   // dilate
+    pass(b, a, 4, 0);   // erode -> base
+    for (int i = t; i < RT_Y * RT_X; i += 256) {
+        int ry = i / RT_X, rx = i - ry * RT_X;
+        int y = gy0 + ry, x = gx0 + rx;
+        if (y < h && x < w) base[f * N + (size_t)y * w + x] = a[(ry + RAP) * RW + rx + RAP] == 1 ? 255 : 0;
+    }
+}
+
 // ---- joints: polygon-moment centroids inside the region rectangle, in cv2.findContours order ----------
 __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restrict__ jm, int h, int w,
                                                         const int *__restrict__ roots, FrameState *__restrict__ st,
@@ -230,6 +292,7 @@ struct VertVisitor {
         if (n < cap) { v[2 * n] = x; v[2 * n + 1] = y; }
         n++;
     }
+    __device__ __forceinline__ bool stop() const { return false; }
 };
 
 __device__ __forceinline__ float normf2(float x, float y) { return (float)sqrt((double)x * x + (double)y * y); }
@@ -559,6 +622,8 @@ struct SegVisitor {
         if (n < 200) { pts[2 * n] = (float)x; pts[2 * n + 1] = (float)y; }
         n++;
     }
+    // expand_line_roi skips contours with more than 200 vertices (util_cylinder.py:169): no need to finish those
+    __device__ __forceinline__ bool stop() const { return n > 200; }
 };
 
 // one thread per fragment: CHAIN_APPROX_SIMPLE vertices (5..200) -> PCA end points, angle, length
@@ -797,20 +862,18 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     (void)hipMemsetAsync(B.cm, 255, total, s);
     CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best, st, B.verts, B.cm);
     // roi masks: (mask & circle_mask & mask_contour) opened 3x3
-    CPE_KLAUNCH(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.hmask, B.cm, B.mc, total, B.tmpA);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_h);
-    CPE_KLAUNCH(k_and3, dim3(grid1(total)), dim3(256), 0, s, B.vmask, B.cm, B.mc, total, B.tmpA);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, B.tmpB);
-    CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, total, h, w, 3, 3, 1, B.roi_v);
+    {
+        const int tiles_x = (w + RT_X - 1) / RT_X, tiles_y = (h + RT_Y - 1) / RT_Y;
+        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.hmask,
+                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, B.roi_h, B.base_h);
+        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.vmask,
+                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, B.roi_v, B.base_v);
+    }
     CPE_CHECK_LAUNCH("masks_stage spot");
     // expansion
     for (int which = 0; which < 2; which++) {
-        const uint8_t *roi = which ? B.roi_v : B.roi_h;
         uint8_t *base = which ? B.base_v : B.base_h;
         uint8_t *exp = which ? B.exp_v : B.exp_h;
-        CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, roi, total, h, w, 3, 3, 1, B.tmpA);
-        CPE_KLAUNCH(k_morph_rect, dim3(grid1(total)), dim3(256), 0, s, B.tmpA, total, h, w, 3, 3, 0, base);
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, base, h, w, which, B.roots, st,
                            B.segs + (size_t)which * n * MAXSEG);

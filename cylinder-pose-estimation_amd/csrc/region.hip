@@ -127,6 +127,7 @@ struct DistVisitor {
         double dx = cx - (double)x, dy = cy - (double)y;
         out[k++] = sqrt(dx * dx + dy * dy);
     }
+    __device__ __forceinline__ bool stop() const { return false; }
 };
 
 // one thread per component: outer border (is_hole = 0) or hole border (is_hole = 1)
@@ -359,6 +360,7 @@ struct HullVisitor {
         hi[x] = max(hi[x], y);
         minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
     }
+    __device__ __forceinline__ bool stop() const { return false; }
 };
 
 __device__ __forceinline__ long long cross3(int ox, int oy, int ax, int ay, int bx, int by)
