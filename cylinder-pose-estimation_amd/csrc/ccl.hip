@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
             unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
             int sx = m ? (x0 + 63 - __clzll(m)) : carry_start;
             L[base + x] = y * w + sx;
-        } else if (valid && !sparse) {
-            L[base + x] = -1;   // sparse passes never read labels of pixels outside the set
+        } else if (valid && sparse != 1) {
+            // sparse 1: labels outside the set are never read; 2: singletons (a growing set will absorb them later)
+            L[base + x] = sparse ? y * w + x : -1;
         }
         bool last_in = (b >> 63) & 1ull;
         if (last_in) {
@@ -290,7 +291,8 @@ int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int i
 
 // One labelling pass.  roots (optional): component list in st[].n_roots / roots; holes_only drops components
 // that reach the border of the working rectangle (needs `touch`); count_mode/cnt as in k_ccl_finish;
-// count_mode 3 only zeroes cnt inside the set's rectangle; sparse: labels of pixels outside the set are left untouched.
+// count_mode 3 only zeroes cnt inside the set's rectangle; sparse 1: labels of pixels outside the set are left untouched,
+// sparse 2: they are written as singletons (own raster index).
 // use_rect: restrict to st[].crect; nrect (optional, int[n][16]): accumulate the set's bounding box there.
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
             uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse)

@@ -11,7 +11,6 @@
 // the hole's raster-first pixel and every outer border at the component's raster-first pixel, so the
 // parallel formulation visits exactly the borders the sequential raster scan does.
 #include "cpe_dev.h"
-#include <stdlib.h>
 
 namespace cpe {
 
@@ -130,21 +129,40 @@ struct DistVisitor {
     __device__ __forceinline__ bool stop() const { return false; }
 };
 
-// one thread per component: outer border (is_hole = 0) or hole border (is_hole = 1)
-__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int thr, int is_hole,
-                                                   const int *__restrict__ roots, const int *__restrict__ cnt,
-                                                   FrameState *__restrict__ st, BlobRec *__restrict__ blobs,
-                                                   int *__restrict__ blob_d, double *__restrict__ dists)
+// ---- threshold sweep bookkeeping: per-frame int counters (SW_STRIDE ints per frame)
+constexpr int NTHR = 17;          // thresholds 50, 60, ..., 210 (SimpleBlobDetector defaults, util_cylinder.py:1836)
+constexpr int SW_STRIDE = 64;
+enum {
+    SW_LA = 0, SW_LB = 1,         // dark (hole) component lists, ping-pong
+    SW_LC = 2, SW_LD = 3,         // bright component lists, ping-pong
+    SW_NDISTS = 4,                // border-distance scratch used by the current trace launch
+    SW_NH = 8,                    // + k: holes of threshold k (length of hl[k])
+    SW_NA = 8 + NTHR,             // + k: blobs of threshold k found on hole borders
+    SW_NB = 8 + 2 * NTHR          // + k: all blobs of threshold k
+};
+static_assert(SW_NB + NTHR <= SW_STRIDE, "sweep counters");
+
+// one thread per component: outer border (is_hole = 0) or hole border (is_hole = 1) of threshold slot `slot`
+__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int thr, int is_hole, int slot,
+                                                   const int *__restrict__ roots, int list_idx, const int *__restrict__ cnt,
+                                                   FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
+                                                   int *__restrict__ blob_d, double *__restrict__ dists, int2 *__restrict__ hl)
 {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nr = min(st[f].n_roots, MAXROOTS);
+    int *S = sw + (size_t)f * SW_STRIDE;
+    const int nr = min(S[list_idx], MAXROOTS);
+    if (is_hole && k == 0) S[SW_NH + slot] = nr;
     if (k >= nr) return;
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
+    const int c = cnt[f * N + root];
+    // the bright pass of this threshold (run later, thresholds descending) needs every hole with its pixel count
+    if (is_hole) hl[((size_t)f * NTHR + slot) * MAXROOTS + k] = make_int2(root, c);
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
-    if (cnt[f * N + root] >= 5000) return;
+    if (c >= 5000) return;
+    BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
     ThreshPred nz{cl + f * N, w, h, thr};
@@ -153,8 +171,6 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     bool ok = trace_border(nz, x0, y0, is_hole != 0, sv, max_steps);
     if (!ok) { st[f].overflow = 1; return; }
     sv.finish();
-    atomicMax(&st[f].pad[is_hole ? 1 : 0], sv.npts);
-    atomicAdd(&st[f].pad[2], sv.npts);
     double m00, m10, m01;
     moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
     if (m00 < 10.0 || m00 >= 5000.0) return;
@@ -162,9 +178,9 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     double cx = m10 / m00, cy = m01 / m00;
     int ix = (int)rint(cx), iy = (int)rint(cy);
     if (nz(ix, iy)) return;  // blobColor = 0: centre pixel must be dark (out-of-image cannot happen for a valid centroid)
-    int bi = atomicAdd(&st[f].n_blobs, 1);
+    int bi = atomicAdd(&S[SW_NB + slot], 1);
     if (bi >= MAXB) { st[f].overflow = 1; return; }
-    int doff = atomicAdd(&st[f].n_dists, sv.npts);
+    int doff = atomicAdd(&S[SW_NDISTS], sv.npts);
     if (doff + sv.npts > MAXD) { st[f].overflow = 1; blob_d[((size_t)f * MAXB + bi) * 2] = -1; blob_d[((size_t)f * MAXB + bi) * 2 + 1] = 0; }
     else {
         DistVisitor dv{cx, cy, dists + (size_t)f * MAXD + doff};
@@ -172,17 +188,20 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
         blob_d[((size_t)f * MAXB + bi) * 2] = doff;
         blob_d[((size_t)f * MAXB + bi) * 2 + 1] = sv.npts;
     }
-    BlobRec &b = blobs[(size_t)f * MAXB + bi];
+    BlobRec &b = blobs[bi];
     b.x = cx; b.y = cy; b.r = 0;
     b.key = root;   // discovery position of the border in the raster scan
 }
 
 // radius = (d[(n-1)/2] + d[n/2]) / 2 of the sorted border distances: one wavefront per blob
-__global__ __launch_bounds__(64) void k_blob_median(FrameState *__restrict__ st, BlobRec *__restrict__ blobs,
+__global__ __launch_bounds__(64) void k_blob_median(const int *__restrict__ sw, int slot, int bright, BlobRec *__restrict__ blobs_all,
                                                     const int *__restrict__ blob_d, const double *__restrict__ dists)
 {
-    const int f = blockIdx.y, bi = blockIdx.x, lane = threadIdx.x;
-    if (bi >= min(st[f].n_blobs, MAXB)) return;
+    const int f = blockIdx.y, lane = threadIdx.x;
+    const int *S = sw + (size_t)f * SW_STRIDE;
+    const int bi = (bright ? min(S[SW_NA + slot], MAXB) : 0) + blockIdx.x;   // blobs appended by the launch just before
+    if (bi >= min(S[SW_NB + slot], MAXB)) return;
+    BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB - (size_t)f * MAXB;
     int doff = blob_d[((size_t)f * MAXB + bi) * 2], n = blob_d[((size_t)f * MAXB + bi) * 2 + 1];
     if (doff < 0 || n <= 0) return;
     const double *d = dists + (size_t)f * MAXD + doff;
@@ -206,89 +225,267 @@ __global__ __launch_bounds__(64) void k_blob_median(FrameState *__restrict__ st,
     if (lane == 0) blobs[(size_t)f * MAXB + bi].r = (v1 + v2) / 2.;
 }
 
-// order this threshold's blobs like cv2.findContours returns contours (latest discovery first) and merge
-// them into the groups (SimpleBlobDetector::detect inner loops); one wavefront per frame
-__global__ __launch_bounds__(64) void k_blob_merge(FrameState *__restrict__ st, const BlobRec *__restrict__ blobs,
-                                                   int *__restrict__ order, Group *__restrict__ groups)
+// for every threshold in ascending order: order its blobs like cv2.findContours returns contours (latest discovery
+// first) and merge them into the groups (SimpleBlobDetector::detect inner loops); one wavefront per frame
+__global__ __launch_bounds__(64) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
+                                                   const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
+                                                   Group *__restrict__ groups)
 {
     __shared__ double sMid[MAXG][3];   // location + radius of each group's middle centre (what the tests read)
     const int f = blockIdx.x, lane = threadIdx.x;
     FrameState &S = st[f];
-    const int nb = min(S.n_blobs, MAXB);
-    const BlobRec *B = blobs + (size_t)f * MAXB;
     int *ord = order + (size_t)f * MAXB;
     Group *G = groups + (size_t)f * MAXG;
-    for (int i = lane; i < nb; i += 64) {
-        int ki = B[i].key, rank = 0;
-        for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0;
-        ord[rank] = i;
-    }
-    const int ng0 = min(S.n_groups, MAXG);
-    for (int j = lane; j < ng0; j += 64) {
-        const Group &g = G[j];
-        const double *mid = g.c[g.n / 2];
-        sMid[j][0] = mid[0]; sMid[j][1] = mid[1]; sMid[j][2] = mid[2];
-    }
-    __syncthreads();
-    int ng = ng0;
-    for (int q = 0; q < nb; q++) {
-        const BlobRec c = B[ord[q]];
-        int jm = INT_MAX;
-        for (int j0 = 0; j0 < ng0 && jm == INT_MAX; j0 += 64) {
-            int j = j0 + lane;
-            bool match = false;
-            if (j < ng0) {
-                double dx = sMid[j][0] - c.x, dy = sMid[j][1] - c.y;
-                double dist = sqrt(dx * dx + dy * dy);
-                bool isNew = dist >= 10.0 && dist >= sMid[j][2] && dist >= c.r;
-                match = !isNew;
+    int ng = 0;
+    for (int t = 0; t < NTHR; t++) {
+        const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + t], MAXB);
+        const BlobRec *B = blobs_all + ((size_t)f * NTHR + t) * MAXB;
+        for (int i = lane; i < nb; i += 64) {
+            int ki = B[i].key, rank = 0;
+            for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0;
+            ord[rank] = i;
+        }
+        __syncthreads();
+        const int ng0 = ng;   // centres of this threshold are only compared with groups of the earlier ones
+        for (int q = 0; q < nb; q++) {
+            const BlobRec c = B[ord[q]];
+            int jm = INT_MAX;
+            for (int j0 = 0; j0 < ng0 && jm == INT_MAX; j0 += 64) {
+                int j = j0 + lane;
+                bool match = false;
+                if (j < ng0) {
+                    double dx = sMid[j][0] - c.x, dy = sMid[j][1] - c.y;
+                    double dist = sqrt(dx * dx + dy * dy);
+                    bool isNew = dist >= 10.0 && dist >= sMid[j][2] && dist >= c.r;
+                    match = !isNew;
+                }
+                unsigned long long bal = __ballot(match);
+                if (bal) jm = j0 + __ffsll((long long)bal) - 1;
             }
-            unsigned long long bal = __ballot(match);
-            if (bal) jm = j0 + __ffsll((long long)bal) - 1;
-        }
-        if (lane == 0) {
-            if (jm != INT_MAX) {
-                Group &g = G[jm];   // only lane 0 ever touches the group lists
-                if (g.n < GCAP) {
-                    int k = g.n++;
-                    while (k > 0 && c.r < g.c[k - 1][2]) {
-                        g.c[k][0] = g.c[k - 1][0]; g.c[k][1] = g.c[k - 1][1]; g.c[k][2] = g.c[k - 1][2];
-                        k--;
-                    }
-                    g.c[k][0] = c.x; g.c[k][1] = c.y; g.c[k][2] = c.r;
-                    const double *mid = g.c[g.n / 2];
-                    sMid[jm][0] = mid[0]; sMid[jm][1] = mid[1]; sMid[jm][2] = mid[2];
+            if (lane == 0) {
+                if (jm != INT_MAX) {
+                    Group &g = G[jm];   // only lane 0 ever touches the group lists
+                    if (g.n < GCAP) {
+                        int k = g.n++;
+                        while (k > 0 && c.r < g.c[k - 1][2]) {
+                            g.c[k][0] = g.c[k - 1][0]; g.c[k][1] = g.c[k - 1][1]; g.c[k][2] = g.c[k - 1][2];
+                            k--;
+                        }
+                        g.c[k][0] = c.x; g.c[k][1] = c.y; g.c[k][2] = c.r;
+                        const double *mid = g.c[g.n / 2];
+                        sMid[jm][0] = mid[0]; sMid[jm][1] = mid[1]; sMid[jm][2] = mid[2];
+                    } else S.overflow = 1;
+                } else if (ng < MAXG) {
+                    Group &g = G[ng];
+                    g.n = 1;
+                    g.c[0][0] = c.x; g.c[0][1] = c.y; g.c[0][2] = c.r;
+                    sMid[ng][0] = c.x; sMid[ng][1] = c.y; sMid[ng][2] = c.r;
                 } else S.overflow = 1;
-            } else if (ng < MAXG) {
-                Group &g = G[ng];
-                g.n = 1;
-                g.c[0][0] = c.x; g.c[0][1] = c.y; g.c[0][2] = c.r;
-            } else S.overflow = 1;
+            }
+            if (jm == INT_MAX && ng < MAXG) ng++;
+            __syncthreads();
         }
-        if (jm == INT_MAX && ng < MAXG) ng++;
         __syncthreads();
     }
-    if (lane == 0) { S.n_groups = ng; S.n_blobs = 0; S.n_dists = 0; }
+    if (lane == 0) S.n_groups = ng;
 }
 
-// enclosed-hole pixel totals per bright component: encl[label of the pixel west of the hole's first pixel] += |hole|
-__global__ __launch_bounds__(64) void k_enclosed(const int *__restrict__ hole_roots, const int *__restrict__ n_hole_roots,
-                                                 const int *__restrict__ cnt_bg, const int *__restrict__ Lfg, int h, int w,
-                                                 int *__restrict__ encl)
+// enclosed-hole pixel totals per bright component of threshold slot k:
+//   encl[component of the pixel west of the hole's first pixel] += |hole|
+__global__ __launch_bounds__(64) void k_enclosed(const int2 *__restrict__ hl, const int *__restrict__ sw, int slot,
+                                                 const int *__restrict__ Pfg, int h, int w, int *__restrict__ encl)
 {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(n_hole_roots[f], MAXROOTS)) return;
+    if (k >= min(sw[(size_t)f * SW_STRIDE + SW_NH + slot], MAXROOTS)) return;
     const size_t N = (size_t)h * w;
-    const int hr = hole_roots[(size_t)f * MAXROOTS + k];
-    const int c = Lfg[f * N + hr - 1];      // flattened label of the bright pixel west of the hole
-    if (c >= 0) atomicAdd(&encl[f * N + c], min(cnt_bg[f * N + hr], 5000));
+    const int2 e = hl[((size_t)f * NTHR + slot) * MAXROOTS + k];
+    const int c = uf_find(Pfg + f * N, e.x - 1);      // bright pixel west of the hole
+    atomicAdd(&encl[f * N + c], min(e.y, 5000));
 }
 
-__global__ void k_save_roots(const FrameState *st, int n, int *n_hole_roots)
+// ---- the 17 binarisations as two growing union-finds ------------------------------------------------------
+// dark set {v <= t} grows with t, bright set {v > t} grows as t falls: every pixel joins each forest once, so a
+// threshold costs one 1-B/px read of the rectangle plus unions / counts for the pixels that are new at it.
+// Roots are always the raster-first pixel of their component (larger root is linked under the smaller).
+//   new at this step: lo < v <= hi;  member: DARK ? v <= hi : v > lo
+struct SwRect { int x0, y0, x1, y1; };
+__device__ __forceinline__ SwRect sw_rect(const FrameState *st, size_t f)
+{
+    return SwRect{st[f].crect[0], st[f].crect[1], st[f].crect[2], st[f].crect[3]};
+}
+
+__global__ __launch_bounds__(256) void k_sw_self(const FrameState *__restrict__ st, int h, int w, int *__restrict__ P)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if ((size_t)i >= N) return;
+    const int y = i / w, x = i - y * w;
+    const SwRect r = sw_rect(st, f);
+    if (y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) return;
+    P[f * N + i] = i;
+}
+
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi,
+                                                  const FrameState *__restrict__ st, int *__restrict__ P, int *__restrict__ sw,
+                                                  int zero_idx)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { sw[f * SW_STRIDE + zero_idx] = 0; sw[f * SW_STRIDE + SW_NDISTS] = 0; }
+    if ((size_t)i >= N) return;
+    const int y = i / w, x = i - y * w;
+    const SwRect r = sw_rect(st, f);
+    if (y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) return;
+    const uint8_t *im = img + f * N;
+    const int v = im[i];
+    if (v <= lo || v > hi) return;
+    int *Pf = P + f * N;
+    // A pair of adjacent members is united by the newer pixel (the later one in raster order when both are new).
+    // Horizontal pairs always; a vertical pair only if the pair one column to the left is not also a member pair
+    // (that pair is connected by induction and joins through the two horizontal links); a diagonal pair only if
+    // neither of the two pixels completing the 2x2 square is a member.
+    const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
+    auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
+    auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
+    auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
+    const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
+    const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
+    const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
+    if (mL) uf_unite(Pf, i, i - 1);
+    if (old(vR)) uf_unite(Pf, i, i + 1);
+    if (mU && !(mL && mem(vUL))) uf_unite(Pf, i, i - w);
+    if (old(vD) && !(mL && mem(vDL))) uf_unite(Pf, i, i + w);
+    if (!DARK) {
+        const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
+        const bool mR = mem(vR);
+        if (!mU) {
+            if (mem(vUR) && !mR) uf_unite(Pf, i, i - w + 1);
+            if (mem(vUL) && !mL) uf_unite(Pf, i, i - w - 1);
+        }
+        if (!mD) {
+            if (old(vDR) && !mR) uf_unite(Pf, i, i + w + 1);
+            if (old(vDL) && !mL) uf_unite(Pf, i, i + w - 1);
+        }
+    }
+}
+
+// rectangle border pixels of the dark set: touch[root] = epoch (such a component is not a hole, now or later)
+__global__ __launch_bounds__(256) void k_sw_touch(const uint8_t *__restrict__ img, int n, int h, int w, int hi,
+                                                  const FrameState *__restrict__ st, const int *__restrict__ P,
+                                                  uint8_t *__restrict__ touch, int epoch)
+{
+    const int per = 2 * w + 2 * h;
+    int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n * per) return;
+    int f = gi / per, k = gi - f * per;
+    const SwRect r = sw_rect(st, f);
+    if (r.x1 < r.x0) return;
+    const int rw = r.x1 - r.x0 + 1, rh = r.y1 - r.y0 + 1;
+    int x, y;
+    if (k < w) { if (k >= rw) return; x = r.x0 + k; y = r.y0; }
+    else if (k < 2 * w) { if (k - w >= rw) return; x = r.x0 + k - w; y = r.y1; }
+    else if (k < 2 * w + h) { if (k - 2 * w >= rh) return; x = r.x0; y = r.y0 + k - 2 * w; }
+    else { if (k - 2 * w - h >= rh) return; x = r.x1; y = r.y0 + k - 2 * w - h; }
+    const size_t N = (size_t)h * w;
+    const int p = y * w + x;
+    if ((int)img[f * N + p] <= hi) touch[f * N + uf_find(P + f * N, p)] = (uint8_t)epoch;
+}
+
+__device__ __forceinline__ void sw_append(bool want, int value, int *counter, int *list, FrameState *S)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long b = __ballot(want);
+    if (!b) return;
+    const int leader = __ffsll((long long)b) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(b));
+    base = __shfl(base, leader, 64);
+    if (want) {
+        int k = base + __popcll(b & ((1ull << lane) - 1ull));
+        if (k < MAXROOTS) list[k] = value;
+        else S->overflow = 1;
+    }
+}
+
+// pixels that joined at this step.  DARK: flatten, add them to their component's pixel count, list the ones that are
+// roots of components away from the rectangle border.  BRIGHT: list the ones that are roots, zero their enclosed total.
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_new(const uint8_t *__restrict__ img, int h, int w, int lo, int hi,
+                                                FrameState *__restrict__ st, int *__restrict__ P, int *__restrict__ acc,
+                                                const uint8_t *__restrict__ touch, int epoch, int *__restrict__ list,
+                                                int *__restrict__ sw, int dst_idx)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool isnew = false;
+    if ((size_t)i < N) {
+        const int y = i / w, x = i - y * w;
+        const SwRect r = sw_rect(st, f);
+        if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) {
+            const int v = img[f * N + i];
+            isnew = v > lo && v <= hi;
+        }
+    }
+    if (!__ballot(isnew)) return;
+    int *Pf = P + f * N;
+    int root = -1;
+    if (isnew) {
+        root = uf_find_c(Pf, i);
+        if (root != i) Pf[i] = root;
+    }
+    bool is_root = isnew && root == i;
+    if (DARK) {
+        is_root = is_root && touch[f * N + i] != (uint8_t)epoch;
+        int key = root;
+        unsigned long long active = __ballot(key >= 0);
+        while (active) {
+            int leader = __ffsll((long long)active) - 1;
+            int lk = __shfl(key, leader, 64);
+            unsigned long long same = __ballot(key == lk) & active;
+            if (lane == leader) atomicAdd(&acc[f * N + lk], __popcll(same));
+            active &= ~same;
+        }
+    } else if (is_root) acc[f * N + i] = 0;
+    sw_append(is_root, i, &sw[f * SW_STRIDE + dst_idx], list + f * MAXROOTS, &st[f]);
+}
+
+// components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
+// Merged into another (DARK): hand its pixel count to the component that absorbed it.
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, const int *__restrict__ src_cnt, int src_stride,
+                                                int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
+                                                int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
+                                                int *__restrict__ list, int *__restrict__ sw, int dst_idx)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int ns = min(src_cnt[f * src_stride], MAXROOTS);
+    bool keep = false;
+    int r = 0;
+    if (k < ns) {
+        r = src[f * MAXROOTS + k];
+        int *Pf = P + f * N;
+        if (DARK) {
+            if (touch[f * N + r] != (uint8_t)epoch) {
+                if (uf_load(Pf, r) == r) keep = true;
+                else atomicAdd(&acc[f * N + uf_find_c(Pf, r)], acc[f * N + r]);
+            }
+        } else {
+            keep = uf_load(Pf, r) == r;
+            if (keep) acc[f * N + r] = 0;
+        }
+    }
+    sw_append(keep, r, &sw[f * SW_STRIDE + dst_idx], list + f * MAXROOTS, &st[f]);
+}
+
+__global__ void k_sw_mark_holes_done(int *sw, int n)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n) n_hole_roots[f] = st[f].n_roots;
+    if (f >= n) return;
+    for (int t = 0; t < NTHR; t++) sw[(size_t)f * SW_STRIDE + SW_NA + t] = sw[(size_t)f * SW_STRIDE + SW_NB + t];
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -495,7 +692,7 @@ __global__ void k_region_reset(FrameState *st, int n, unsigned long long *best)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
-    st[f].n_blobs = 0; st[f].n_dists = 0; st[f].n_groups = 0; st[f].n_kp = 0;
+    st[f].n_groups = 0; st[f].n_kp = 0;
     best[f] = 0;
 }
 
@@ -526,22 +723,60 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
     // every brighter set and every hole of every binarisation lies inside it
     if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
-    for (int thr = 50; thr < 220; thr += 10) {
-        // enclosed dark components (4-conn): hole borders; pixel counts in B.cnt
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots2, true, B.touch, 1, B.cnt, 1, nullptr, st, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_save_roots, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameState *)st, n, B.n_roots2);
-        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 1, B.roots2, B.cnt, st, B.blobs,
-                    B.blob_d, B.dists);
-        // bright components (8-conn): outer borders; B.cnt2 = pixels of the holes each one encloses
-        if ((rc = ccl_run(B.cl, n, h, w, thr, 0, 1, B.lab2, B.roots, false, nullptr, 3, B.cnt2, 1, nullptr, st, s, 1)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_enclosed, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const int *)B.roots2, (const int *)B.n_roots2,
-                    (const int *)B.cnt, (const int *)B.lab2, h, w, B.cnt2);
-        CPE_KLAUNCH(k_blob_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.cl, h, w, thr, 0, B.roots, B.cnt2, st, B.blobs,
-                    B.blob_d, B.dists);
-        CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, st, B.blobs, B.blob_d, B.dists);
-        CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, B.blobs, B.order, B.groups);
-        CPE_CHECK_LAUNCH("blob threshold pass");
+    (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
+    (void)hipMemsetAsync(B.touch, 0, total, s);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXROOTS / 256, n), gtrace(MAXROOTS / 64, n);
+    const int per = 2 * w + 2 * h;
+    int *dark_list[2] = {B.roots2, B.roots3}, *bright_list[2] = {B.roots, B.roots4};
+    // ---- ascending thresholds: enclosed dark components (4-conn) -> hole borders; pixel counts in B.cnt
+    for (int k = 0; k < NTHR; k++) {
+        const int thr = 50 + 10 * k, dst = k & 1, epoch = k + 1;
+        if (k == 0) {
+            // the bulk of the dark set: run-based labelling, flattened; pixels outside it start as singletons
+            if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, s, 2)) != CPE_OK) return rc;
+            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
+                        (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.roots, (const int *)&st[0].n_roots,
+                        (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
+                        dark_list[dst], B.sw, SW_LA + dst);
+        } else {
+            CPE_KLAUNCH(k_sw_unite<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, (const FrameState *)st,
+                        B.lab, B.sw, SW_LA + dst);
+            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
+                        (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
+            CPE_KLAUNCH(k_sw_new<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, st, B.lab, B.cnt,
+                        (const uint8_t *)B.touch, epoch, dark_list[dst], B.sw, SW_LA + dst);
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)dark_list[dst ^ 1], (const int *)(B.sw + SW_LA + (dst ^ 1)),
+                        SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, dark_list[dst], B.sw, SW_LA + dst);
+        }
+        CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, thr, 1, k, (const int *)dark_list[dst], SW_LA + dst,
+                    (const int *)B.cnt, st, B.sw, B.blobs, B.blob_d, B.dists, B.hl);
+        CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, (const int *)B.sw, k, 0, B.blobs, (const int *)B.blob_d,
+                    (const double *)B.dists);
+        CPE_CHECK_LAUNCH("blob sweep (holes)");
     }
+    CPE_KLAUNCH(k_sw_mark_holes_done, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
+    // ---- descending thresholds: bright components (8-conn) -> outer borders; B.cnt2 = pixels of the holes each encloses
+    CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
+    for (int j = 0; j < NTHR; j++) {
+        const int k = NTHR - 1 - j, thr = 50 + 10 * k, dst = j & 1;
+        const int hi = j == 0 ? 255 : thr + 10;
+        CPE_KLAUNCH(k_sw_unite<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, (const FrameState *)st, B.lab2,
+                    B.sw, SW_LC + dst);
+        CPE_KLAUNCH(k_sw_new<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, st, B.lab2, B.cnt2,
+                    (const uint8_t *)nullptr, 0, bright_list[dst], B.sw, SW_LC + dst);
+        if (j > 0)
+            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)bright_list[dst ^ 1], (const int *)(B.sw + SW_LC + (dst ^ 1)),
+                        SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, 0, bright_list[dst], B.sw, SW_LC + dst);
+        CPE_KLAUNCH(k_enclosed, gtrace, dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
+        CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, thr, 0, k, (const int *)bright_list[dst], SW_LC + dst,
+                    (const int *)B.cnt2, st, B.sw, B.blobs, B.blob_d, B.dists, (int2 *)nullptr);
+        CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, (const int *)B.sw, k, 1, B.blobs, (const int *)B.blob_d,
+                    (const double *)B.dists);
+        CPE_CHECK_LAUNCH("blob sweep (bright)");
+    }
+    CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
+    CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
     CPE_KLAUNCH(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
