@@ -61,8 +61,8 @@ struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
 // stage buffer bundles (all device pointers into the caller's workspace, plane-major [n][...])
 struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
-    int *lab, *cnt, *lab2, *cnt2, *roots, *roots2, *roots3, *roots4, *sw, *nrect;
-    int2 *hl;
+    int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect;
+    int2 *hl, *bl;   // per-threshold component lists of the blob sweep (dark / bright)
     unsigned int *hist;
     uint8_t *lut;
     BlobRec *blobs;

@@ -131,37 +131,35 @@ struct DistVisitor {
 
 // ---- threshold sweep bookkeeping: per-frame int counters (SW_STRIDE ints per frame)
 constexpr int NTHR = 17;          // thresholds 50, 60, ..., 210 (SimpleBlobDetector defaults, util_cylinder.py:1836)
-constexpr int SW_STRIDE = 64;
+constexpr int SW_STRIDE = 128;
 enum {
-    SW_LA = 0, SW_LB = 1,         // dark (hole) component lists, ping-pong
-    SW_LC = 2, SW_LD = 3,         // bright component lists, ping-pong
-    SW_NDISTS = 4,                // border-distance scratch used by the current trace launch
-    SW_NH = 8,                    // + k: holes of threshold k (length of hl[k])
-    SW_NA = 8 + NTHR,             // + k: blobs of threshold k found on hole borders
-    SW_NB = 8 + 2 * NTHR          // + k: all blobs of threshold k
+    SW_NH = 8,                    // + k: dark components away from the rectangle border at threshold k (length of hl[k])
+    SW_NL = SW_NH + NTHR,         // + k: bright components at threshold k (length of bl[k])
+    SW_NB = SW_NL + NTHR,         // + k: blobs of threshold k
+    SW_ND = SW_NB + NTHR          // + k: border distances stored for threshold k
 };
-static_assert(SW_NB + NTHR <= SW_STRIDE, "sweep counters");
+static_assert(SW_ND + NTHR <= SW_STRIDE, "sweep counters");
 
-// one thread per component: outer border (is_hole = 0) or hole border (is_hole = 1) of threshold slot `slot`
-__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int thr, int is_hole, int slot,
-                                                   const int *__restrict__ roots, int list_idx, const int *__restrict__ cnt,
+// one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
+// lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
+__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int is_hole,
+                                                   const int2 *__restrict__ lists, int cnt_base,
                                                    FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
-                                                   int *__restrict__ blob_d, double *__restrict__ dists, int2 *__restrict__ hl)
+                                                   int *__restrict__ blob_d_all, double *__restrict__ dists_all)
 {
-    const int f = blockIdx.y;
+    const int f = blockIdx.y, slot = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int thr = 50 + 10 * slot;
     int *S = sw + (size_t)f * SW_STRIDE;
-    const int nr = min(S[list_idx], MAXROOTS);
-    if (is_hole && k == 0) S[SW_NH + slot] = nr;
-    if (k >= nr) return;
+    if (k >= min(S[cnt_base + slot], MAXROOTS)) return;
     const size_t N = (size_t)h * w;
-    const int root = roots[(size_t)f * MAXROOTS + k];
-    const int c = cnt[f * N + root];
-    // the bright pass of this threshold (run later, thresholds descending) needs every hole with its pixel count
-    if (is_hole) hl[((size_t)f * NTHR + slot) * MAXROOTS + k] = make_int2(root, c);
+    const int2 e = lists[((size_t)f * NTHR + slot) * MAXROOTS + k];
+    const int root = e.x;
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
-    if (c >= 5000) return;
+    if (e.y >= 5000) return;
+    int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
+    double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXD;
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
@@ -180,13 +178,13 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     if (nz(ix, iy)) return;  // blobColor = 0: centre pixel must be dark (out-of-image cannot happen for a valid centroid)
     int bi = atomicAdd(&S[SW_NB + slot], 1);
     if (bi >= MAXB) { st[f].overflow = 1; return; }
-    int doff = atomicAdd(&S[SW_NDISTS], sv.npts);
-    if (doff + sv.npts > MAXD) { st[f].overflow = 1; blob_d[((size_t)f * MAXB + bi) * 2] = -1; blob_d[((size_t)f * MAXB + bi) * 2 + 1] = 0; }
+    int doff = atomicAdd(&S[SW_ND + slot], sv.npts);
+    if (doff + sv.npts > MAXD) { st[f].overflow = 1; blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
     else {
-        DistVisitor dv{cx, cy, dists + (size_t)f * MAXD + doff};
+        DistVisitor dv{cx, cy, dists + doff};
         trace_border(nz, x0, y0, is_hole != 0, dv, max_steps);
-        blob_d[((size_t)f * MAXB + bi) * 2] = doff;
-        blob_d[((size_t)f * MAXB + bi) * 2 + 1] = sv.npts;
+        blob_d[bi * 2] = doff;
+        blob_d[bi * 2 + 1] = sv.npts;
     }
     BlobRec &b = blobs[bi];
     b.x = cx; b.y = cy; b.r = 0;
@@ -194,35 +192,36 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
 }
 
 // radius = (d[(n-1)/2] + d[n/2]) / 2 of the sorted border distances: one wavefront per blob
-__global__ __launch_bounds__(64) void k_blob_median(const int *__restrict__ sw, int slot, int bright, BlobRec *__restrict__ blobs_all,
-                                                    const int *__restrict__ blob_d, const double *__restrict__ dists)
+__global__ __launch_bounds__(64) void k_blob_median(const int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
+                                                    const int *__restrict__ blob_d_all, const double *__restrict__ dists_all)
 {
-    const int f = blockIdx.y, lane = threadIdx.x;
-    const int *S = sw + (size_t)f * SW_STRIDE;
-    const int bi = (bright ? min(S[SW_NA + slot], MAXB) : 0) + blockIdx.x;   // blobs appended by the launch just before
-    if (bi >= min(S[SW_NB + slot], MAXB)) return;
-    BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB - (size_t)f * MAXB;
-    int doff = blob_d[((size_t)f * MAXB + bi) * 2], n = blob_d[((size_t)f * MAXB + bi) * 2 + 1];
-    if (doff < 0 || n <= 0) return;
-    const double *d = dists + (size_t)f * MAXD + doff;
-    const int k1 = (n - 1) / 2, k2 = n / 2;
-    double v1 = 0, v2 = 0;
-    for (int i = lane; i < n; i += 64) {
-        double di = d[i];
-        int rank = 0;
-        for (int j = 0; j < n; j++) {
-            double dj = d[j];
-            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+    const int f = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
+    const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + slot], MAXB);
+    BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
+    const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
+    for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+        int doff = blob_d[bi * 2], n = blob_d[bi * 2 + 1];
+        if (doff < 0 || n <= 0) continue;
+        const double *d = dists_all + ((size_t)f * NTHR + slot) * MAXD + doff;
+        const int k1 = (n - 1) / 2, k2 = n / 2;
+        double v1 = 0, v2 = 0;
+        for (int i = lane; i < n; i += 64) {
+            double di = d[i];
+            int rank = 0;
+            for (int j = 0; j < n; j++) {
+                double dj = d[j];
+                rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+            }
+            if (rank == k1) v1 = di;
+            if (rank == k2) v2 = di;
         }
-        if (rank == k1) v1 = di;
-        if (rank == k2) v2 = di;
+        // exactly one lane holds each value
+        for (int off = 32; off >= 1; off >>= 1) {
+            v1 = fmax(v1, __shfl_xor(v1, off, 64));
+            v2 = fmax(v2, __shfl_xor(v2, off, 64));
+        }
+        if (lane == 0) blobs[bi].r = (v1 + v2) / 2.;
     }
-    // exactly one lane holds each value
-    for (int off = 32; off >= 1; off >>= 1) {
-        v1 = fmax(v1, __shfl_xor(v1, off, 64));
-        v2 = fmax(v2, __shfl_xor(v2, off, 64));
-    }
-    if (lane == 0) blobs[(size_t)f * MAXB + bi].r = (v1 + v2) / 2.;
 }
 
 // for every threshold in ascending order: order its blobs like cv2.findContours returns contours (latest discovery
@@ -328,12 +327,10 @@ __global__ __launch_bounds__(256) void k_sw_self(const FrameState *__restrict__ 
 
 template <bool DARK>
 __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi,
-                                                  const FrameState *__restrict__ st, int *__restrict__ P, int *__restrict__ sw,
-                                                  int zero_idx)
+                                                  const FrameState *__restrict__ st, int *__restrict__ P)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) { sw[f * SW_STRIDE + zero_idx] = 0; sw[f * SW_STRIDE + SW_NDISTS] = 0; }
     if ((size_t)i >= N) return;
     const int y = i / w, x = i - y * w;
     const SwRect r = sw_rect(st, f);
@@ -393,7 +390,7 @@ __global__ __launch_bounds__(256) void k_sw_touch(const uint8_t *__restrict__ im
     if ((int)img[f * N + p] <= hi) touch[f * N + uf_find(P + f * N, p)] = (uint8_t)epoch;
 }
 
-__device__ __forceinline__ void sw_append(bool want, int value, int *counter, int *list, FrameState *S)
+__device__ __forceinline__ void sw_append(bool want, int value, int *counter, int2 *list, FrameState *S)
 {
     const int lane = threadIdx.x & 63;
     unsigned long long b = __ballot(want);
@@ -404,7 +401,7 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
     base = __shfl(base, leader, 64);
     if (want) {
         int k = base + __popcll(b & ((1ull << lane) - 1ull));
-        if (k < MAXROOTS) list[k] = value;
+        if (k < MAXROOTS) list[k].x = value;
         else S->overflow = 1;
     }
 }
@@ -414,8 +411,8 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
 template <bool DARK>
 __global__ __launch_bounds__(256) void k_sw_new(const uint8_t *__restrict__ img, int h, int w, int lo, int hi,
                                                 FrameState *__restrict__ st, int *__restrict__ P, int *__restrict__ acc,
-                                                const uint8_t *__restrict__ touch, int epoch, int *__restrict__ list,
-                                                int *__restrict__ sw, int dst_idx)
+                                                const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
+                                                int *__restrict__ sw, int cnt_base, int slot)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -449,24 +446,25 @@ __global__ __launch_bounds__(256) void k_sw_new(const uint8_t *__restrict__ img,
             active &= ~same;
         }
     } else if (is_root) acc[f * N + i] = 0;
-    sw_append(is_root, i, &sw[f * SW_STRIDE + dst_idx], list + f * MAXROOTS, &st[f]);
+    sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXROOTS, &st[f]);
 }
 
 // components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
 // Merged into another (DARK): hand its pixel count to the component that absorbed it.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, const int *__restrict__ src_cnt, int src_stride,
+__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_elem_stride,
+                                                const int *__restrict__ src_cnt, int src_cnt_stride,
                                                 int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
                                                 int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
-                                                int *__restrict__ list, int *__restrict__ sw, int dst_idx)
+                                                int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int ns = min(src_cnt[f * src_stride], MAXROOTS);
+    const int ns = min(src_cnt[f * src_cnt_stride], MAXROOTS);
     bool keep = false;
     int r = 0;
     if (k < ns) {
-        r = src[f * MAXROOTS + k];
+        r = src[f * src_frame_stride + (size_t)k * src_elem_stride];
         int *Pf = P + f * N;
         if (DARK) {
             if (touch[f * N + r] != (uint8_t)epoch) {
@@ -478,14 +476,18 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, con
             if (keep) acc[f * N + r] = 0;
         }
     }
-    sw_append(keep, r, &sw[f * SW_STRIDE + dst_idx], list + f * MAXROOTS, &st[f]);
+    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXROOTS, &st[f]);
 }
 
-__global__ void k_sw_mark_holes_done(int *sw, int n)
+// freeze the per-component totals of threshold slot `slot` next to the roots: the accumulator plane moves on
+__global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, const int *__restrict__ sw, int cnt_base, int slot,
+                                                 int h, int w, const int *__restrict__ acc)
 {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    for (int t = 0; t < NTHR; t++) sw[(size_t)f * SW_STRIDE + SW_NA + t] = sw[(size_t)f * SW_STRIDE + SW_NB + t];
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(sw[f * SW_STRIDE + cnt_base + slot], MAXROOTS)) return;
+    int2 &e = lists[(f * NTHR + slot) * MAXROOTS + k];
+    e.y = acc[f * N + e.x];
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -725,56 +727,54 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXROOTS / 256, n), gtrace(MAXROOTS / 64, n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXROOTS / 256, n), gtrace(MAXROOTS / 64, n, NTHR);
     const int per = 2 * w + 2 * h;
-    int *dark_list[2] = {B.roots2, B.roots3}, *bright_list[2] = {B.roots, B.roots4};
-    // ---- ascending thresholds: enclosed dark components (4-conn) -> hole borders; pixel counts in B.cnt
+    const size_t lstride = (size_t)NTHR * MAXROOTS * 2;   // ints per frame of a list array
+    // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count)
     for (int k = 0; k < NTHR; k++) {
-        const int thr = 50 + 10 * k, dst = k & 1, epoch = k + 1;
+        const int thr = 50 + 10 * k, epoch = k + 1;
         if (k == 0) {
             // the bulk of the dark set: run-based labelling, flattened; pixels outside it start as singletons
             if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, s, 2)) != CPE_OK) return rc;
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.roots, (const int *)&st[0].n_roots,
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.roots, (size_t)MAXROOTS, 1, (const int *)&st[0].n_roots,
                         (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
-                        dark_list[dst], B.sw, SW_LA + dst);
+                        B.hl, B.sw, (int)SW_NH, k);
         } else {
-            CPE_KLAUNCH(k_sw_unite<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, (const FrameState *)st,
-                        B.lab, B.sw, SW_LA + dst);
+            CPE_KLAUNCH(k_sw_unite<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, (const FrameState *)st, B.lab);
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             CPE_KLAUNCH(k_sw_new<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, st, B.lab, B.cnt,
-                        (const uint8_t *)B.touch, epoch, dark_list[dst], B.sw, SW_LA + dst);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)dark_list[dst ^ 1], (const int *)(B.sw + SW_LA + (dst ^ 1)),
-                        SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, dark_list[dst], B.sw, SW_LA + dst);
+                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k);
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.hl + (size_t)(k - 1) * MAXROOTS * 2, lstride, 2,
+                        (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
+                        B.hl, B.sw, (int)SW_NH, k);
         }
-        CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, thr, 1, k, (const int *)dark_list[dst], SW_LA + dst,
-                    (const int *)B.cnt, st, B.sw, B.blobs, B.blob_d, B.dists, B.hl);
-        CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, (const int *)B.sw, k, 0, B.blobs, (const int *)B.blob_d,
-                    (const double *)B.dists);
-        CPE_CHECK_LAUNCH("blob sweep (holes)");
+        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.hl, (const int *)B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt);
+        CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
-    CPE_KLAUNCH(k_sw_mark_holes_done, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
-    // ---- descending thresholds: bright components (8-conn) -> outer borders; B.cnt2 = pixels of the holes each encloses
+    CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, 1, (const int2 *)B.hl, (int)SW_NH, st, B.sw, B.blobs,
+                B.blob_d, B.dists);
+    // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
     for (int j = 0; j < NTHR; j++) {
-        const int k = NTHR - 1 - j, thr = 50 + 10 * k, dst = j & 1;
+        const int k = NTHR - 1 - j, thr = 50 + 10 * k;
         const int hi = j == 0 ? 255 : thr + 10;
-        CPE_KLAUNCH(k_sw_unite<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, (const FrameState *)st, B.lab2,
-                    B.sw, SW_LC + dst);
+        CPE_KLAUNCH(k_sw_unite<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, (const FrameState *)st, B.lab2);
         CPE_KLAUNCH(k_sw_new<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, st, B.lab2, B.cnt2,
-                    (const uint8_t *)nullptr, 0, bright_list[dst], B.sw, SW_LC + dst);
+                    (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, k);
         if (j > 0)
-            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)bright_list[dst ^ 1], (const int *)(B.sw + SW_LC + (dst ^ 1)),
-                        SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, 0, bright_list[dst], B.sw, SW_LC + dst);
-        CPE_KLAUNCH(k_enclosed, gtrace, dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
-        CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, thr, 0, k, (const int *)bright_list[dst], SW_LC + dst,
-                    (const int *)B.cnt2, st, B.sw, B.blobs, B.blob_d, B.dists, (int2 *)nullptr);
-        CPE_KLAUNCH(k_blob_median, dim3(MAXB, n), dim3(64), 0, s, (const int *)B.sw, k, 1, B.blobs, (const int *)B.blob_d,
-                    (const double *)B.dists);
+            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXROOTS * 2, lstride, 2,
+                        (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, 0,
+                        B.bl, B.sw, (int)SW_NL, k);
+        CPE_KLAUNCH(k_enclosed, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
+        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.bl, (const int *)B.sw, (int)SW_NL, k, h, w, (const int *)B.cnt2);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
+    CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, 0, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
+                B.blob_d, B.dists);
+    CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, (const int *)B.sw, B.blobs, (const int *)B.blob_d, (const double *)B.dists);
     CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);

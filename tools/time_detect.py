@@ -23,4 +23,4 @@ print('fvals', out['fvals'].tolist())
 cpe_amd.lib.profile(True)
 det = api.detect_grid_batch(frames, ws); torch.cuda.synchronize()
 rep = cpe_amd.lib.profile_report(); cpe_amd.lib.profile(False)
-print('event profile:', ' | '.join(f"{r[0].split('::')[-1]} x{r[1]} {r[2]:.1f}ms" for r in rep[:10]))
+print('event profile:', ' | '.join(f"{r[0].split('::')[-1]} x{r[1]} {r[2]:.1f}ms" for r in rep[:int(os.environ.get("CPE_TOP", "10"))]), "| total %.1f ms" % sum(r[2] for r in rep))
