@@ -61,7 +61,7 @@ struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
 // stage buffer bundles (all device pointers into the caller's workspace, plane-major [n][...])
 struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
-    int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect;
+    int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
     int2 *hl, *bl;   // per-threshold component lists of the blob sweep (dark / bright)
     unsigned int *hist;
     uint8_t *lut;

@@ -131,14 +131,18 @@ struct DistVisitor {
 
 // ---- threshold sweep bookkeeping: per-frame int counters (SW_STRIDE ints per frame)
 constexpr int NTHR = 17;          // thresholds 50, 60, ..., 210 (SimpleBlobDetector defaults, util_cylinder.py:1836)
-constexpr int SW_STRIDE = 128;
+constexpr int SW_STRIDE = 160;
+constexpr int NBK = NTHR + 1;     // grey-level buckets: 0: v <= 50, b: 50 + 10 (b - 1) < v <= 50 + 10 b, 17: v > 210
 enum {
     SW_NH = 8,                    // + k: dark components away from the rectangle border at threshold k (length of hl[k])
     SW_NL = SW_NH + NTHR,         // + k: bright components at threshold k (length of bl[k])
     SW_NB = SW_NL + NTHR,         // + k: blobs of threshold k
-    SW_ND = SW_NB + NTHR          // + k: border distances stored for threshold k
+    SW_ND = SW_NB + NTHR,         // + k: border distances stored for threshold k
+    SW_BS = SW_ND + NTHR,         // + b: pixels of bucket b inside the rectangle
+    SW_BO = SW_BS + NBK,          // + b: first entry of bucket b in the bucket plane
+    SW_BC = SW_BO + NBK           // + b: fill cursor
 };
-static_assert(SW_ND + NTHR <= SW_STRIDE, "sweep counters");
+static_assert(SW_BC + NBK <= SW_STRIDE, "sweep counters");
 
 // one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
 // lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
@@ -325,45 +329,102 @@ __global__ __launch_bounds__(256) void k_sw_self(const FrameState *__restrict__ 
     P[f * N + i] = i;
 }
 
+// ---- pixels of the rectangle sorted by the step at which they join: bucket b is new for the dark set at threshold
+// slot b and for the bright set at slot b - 1, so every later kernel of the sweep runs over a dense list
+__device__ __forceinline__ int sw_level(int v) { return v <= 50 ? 0 : min(NTHR, (v - 41) / 10); }
+constexpr int BK_CHUNK = 4096;    // pixels per workgroup of the two bucket passes
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img, int h, int w, const FrameState *__restrict__ st,
+                                                 int *__restrict__ sw, int *__restrict__ bk)
+{
+    __shared__ int s_cnt[NBK], s_base[NBK];
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int t = threadIdx.x;
+    if (t < NBK) s_cnt[t] = 0;
+    __syncthreads();
+    const SwRect r = sw_rect(st, f);
+    const uint8_t *im = img + f * N;
+    int lev[BK_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < BK_CHUNK / 256; k++) {
+        const size_t i = (size_t)blockIdx.x * BK_CHUNK + k * 256 + t;
+        int l = 0;
+        if (i < N) {
+            const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+            if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) l = sw_level(im[i]);
+        }
+        lev[k] = l;
+        if (l && !SCATTER) atomicAdd(&s_cnt[l], 1);
+        if (l && SCATTER) lev[k] = l | (atomicAdd(&s_cnt[l], 1) << 8);   // rank inside this workgroup's share
+    }
+    __syncthreads();
+    int *S = sw + f * SW_STRIDE;
+    if (!SCATTER) {
+        if (t > 0 && t < NBK && s_cnt[t]) atomicAdd(&S[SW_BS + t], s_cnt[t]);
+        return;
+    }
+    if (t > 0 && t < NBK) s_base[t] = s_cnt[t] ? atomicAdd(&S[SW_BC + t], s_cnt[t]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BK_CHUNK / 256; k++) {
+        const int l = lev[k] & 255;
+        if (l) bk[f * N + s_base[l] + (lev[k] >> 8)] = (int)((size_t)blockIdx.x * BK_CHUNK + k * 256 + t);
+    }
+}
+
+__global__ void k_bk_scan(int *sw, int n)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    int *S = sw + (size_t)f * SW_STRIDE;
+    int off = 0;
+    for (int b = 1; b < NBK; b++) { S[SW_BO + b] = off; S[SW_BC + b] = off; off += S[SW_BS + b]; }
+}
+
+constexpr int SW_GRID = 96;       // workgroups per frame of the kernels that walk one bucket
+
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi,
-                                                  const FrameState *__restrict__ st, int *__restrict__ P)
+__global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
+                                                  const FrameState *__restrict__ st, const int *__restrict__ sw,
+                                                  const int *__restrict__ bk, int *__restrict__ P)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if ((size_t)i >= N) return;
-    const int y = i / w, x = i - y * w;
+    const int *S = sw + f * SW_STRIDE;
+    const int nb = S[SW_BS + bucket];
+    const int *list = bk + f * N + S[SW_BO + bucket];
     const SwRect r = sw_rect(st, f);
-    if (y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) return;
     const uint8_t *im = img + f * N;
-    const int v = im[i];
-    if (v <= lo || v > hi) return;
     int *Pf = P + f * N;
     // A pair of adjacent members is united by the newer pixel (the later one in raster order when both are new).
     // Horizontal pairs always; a vertical pair only if the pair one column to the left is not also a member pair
     // (that pair is connected by induction and joins through the two horizontal links); a diagonal pair only if
     // neither of the two pixels completing the 2x2 square is a member.
-    const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
-    auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
     auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
     auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
-    const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
-    const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
-    const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
-    if (mL) uf_unite(Pf, i, i - 1);
-    if (old(vR)) uf_unite(Pf, i, i + 1);
-    if (mU && !(mL && mem(vUL))) uf_unite(Pf, i, i - w);
-    if (old(vD) && !(mL && mem(vDL))) uf_unite(Pf, i, i + w);
-    if (!DARK) {
-        const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
-        const bool mR = mem(vR);
-        if (!mU) {
-            if (mem(vUR) && !mR) uf_unite(Pf, i, i - w + 1);
-            if (mem(vUL) && !mL) uf_unite(Pf, i, i - w - 1);
-        }
-        if (!mD) {
-            if (old(vDR) && !mR) uf_unite(Pf, i, i + w + 1);
-            if (old(vDL) && !mL) uf_unite(Pf, i, i + w - 1);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nb; e += SW_GRID * 256) {
+        const int i = list[e];
+        const int y = i / w, x = i - y * w;
+        const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
+        auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
+        const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
+        const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
+        const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
+        if (mL) uf_unite(Pf, i, i - 1);
+        if (old(vR)) uf_unite(Pf, i, i + 1);
+        if (mU && !(mL && mem(vUL))) uf_unite(Pf, i, i - w);
+        if (old(vD) && !(mL && mem(vDL))) uf_unite(Pf, i, i + w);
+        if (!DARK) {
+            const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
+            const bool mR = mem(vR);
+            if (!mU) {
+                if (mem(vUR) && !mR) uf_unite(Pf, i, i - w + 1);
+                if (mem(vUL) && !mL) uf_unite(Pf, i, i - w - 1);
+            }
+            if (!mD) {
+                if (old(vDR) && !mR) uf_unite(Pf, i, i + w + 1);
+                if (old(vDL) && !mL) uf_unite(Pf, i, i + w - 1);
+            }
         }
     }
 }
@@ -407,46 +468,44 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
 }
 
 // pixels that joined at this step.  DARK: flatten, add them to their component's pixel count, list the ones that are
-// roots of components away from the rectangle border.  BRIGHT: list the ones that are roots, zero their enclosed total.
+// roots of components away from the rectangle border.  BRIGHT: flatten, list the ones that are roots, zero their
+// enclosed total.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_new(const uint8_t *__restrict__ img, int h, int w, int lo, int hi,
-                                                FrameState *__restrict__ st, int *__restrict__ P, int *__restrict__ acc,
+__global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, FrameState *__restrict__ st, const int *__restrict__ bk,
+                                                int *__restrict__ P, int *__restrict__ acc,
                                                 const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
                                                 int *__restrict__ sw, int cnt_base, int slot)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    bool isnew = false;
-    if ((size_t)i < N) {
-        const int y = i / w, x = i - y * w;
-        const SwRect r = sw_rect(st, f);
-        if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) {
-            const int v = img[f * N + i];
-            isnew = v > lo && v <= hi;
-        }
-    }
-    if (!__ballot(isnew)) return;
+    const int *S = sw + f * SW_STRIDE;
+    const int nb = S[SW_BS + bucket];
+    const int *list = bk + f * N + S[SW_BO + bucket];
     int *Pf = P + f * N;
-    int root = -1;
-    if (isnew) {
-        root = uf_find_c(Pf, i);
-        if (root != i) Pf[i] = root;
-    }
-    bool is_root = isnew && root == i;
-    if (DARK) {
-        is_root = is_root && touch[f * N + i] != (uint8_t)epoch;
-        int key = root;
-        unsigned long long active = __ballot(key >= 0);
-        while (active) {
-            int leader = __ffsll((long long)active) - 1;
-            int lk = __shfl(key, leader, 64);
-            unsigned long long same = __ballot(key == lk) & active;
-            if (lane == leader) atomicAdd(&acc[f * N + lk], __popcll(same));
-            active &= ~same;
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += SW_GRID * 256) {
+        const int e = e0 + threadIdx.x;
+        const bool isnew = e < nb;
+        int i = -1, root = -1;
+        if (isnew) {
+            i = list[e];
+            root = uf_find_c(Pf, i);
+            if (root != i) Pf[i] = root;
         }
-    } else if (is_root) acc[f * N + i] = 0;
-    sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXROOTS, &st[f]);
+        bool is_root = isnew && root == i;
+        if (DARK) {
+            is_root = is_root && touch[f * N + i] != (uint8_t)epoch;
+            int key = root;
+            unsigned long long active = __ballot(key >= 0);
+            while (active) {
+                int leader = __ffsll((long long)active) - 1;
+                int lk = __shfl(key, leader, 64);
+                unsigned long long same = __ballot(key == lk) & active;
+                if (lane == leader) atomicAdd(&acc[f * N + lk], __popcll(same));
+                active &= ~same;
+            }
+        } else if (is_root) acc[f * N + i] = 0;
+        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXROOTS, &st[f]);
+    }
 }
 
 // components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
@@ -727,7 +786,14 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXROOTS / 256, n), gtrace(MAXROOTS / 64, n, NTHR);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXROOTS / 256, n), gtrace(MAXROOTS / 64, n, NTHR), gbk(SW_GRID, n);
+    {
+        const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
+        CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
+        CPE_KLAUNCH(k_bk_scan, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
+        CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
+        CPE_CHECK_LAUNCH("grey-level buckets");
+    }
     const int per = 2 * w + 2 * h;
     const size_t lstride = (size_t)NTHR * MAXROOTS * 2;   // ints per frame of a list array
     // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count)
@@ -742,10 +808,11 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k);
         } else {
-            CPE_KLAUNCH(k_sw_unite<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, (const FrameState *)st, B.lab);
+            CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
+                        (const int *)B.sw, (const int *)B.bk, B.lab);
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_new<true>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, st, B.lab, B.cnt,
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, s, h, w, k, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k);
             CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.hl + (size_t)(k - 1) * MAXROOTS * 2, lstride, 2,
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
@@ -761,8 +828,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     for (int j = 0; j < NTHR; j++) {
         const int k = NTHR - 1 - j, thr = 50 + 10 * k;
         const int hi = j == 0 ? 255 : thr + 10;
-        CPE_KLAUNCH(k_sw_unite<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, (const FrameState *)st, B.lab2);
-        CPE_KLAUNCH(k_sw_new<false>, gpx, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, st, B.lab2, B.cnt2,
+        CPE_KLAUNCH(k_sw_unite<false>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, k + 1, (const FrameState *)st,
+                    (const int *)B.sw, (const int *)B.bk, B.lab2);
+        CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, st, (const int *)B.bk, B.lab2, B.cnt2,
                     (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, k);
         if (j > 0)
             CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXROOTS * 2, lstride, 2,
