@@ -267,7 +267,46 @@ __global__ void k_ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int o
     // op 3: keep crect (a superset of the next, smaller set), accumulator already empty
 }
 
+// one wavefront per 64 pixels of a row: a ballot per threshold is the 64-bit group of that plane
+__global__ __launch_bounds__(256) void k_bitplanes(const uint8_t *__restrict__ img, int rows_total, int h, int w, int thr0, int step,
+                                                   int nplanes, uint32_t *__restrict__ planes)
+{
+    const int lane = threadIdx.x & 63;
+    const int chunks = (w + 63) >> 6;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (long long)rows_total * chunks) return;
+    const int row = (int)(gw / chunks), c = (int)(gw - (long long)row * chunks);
+    const int f = row / h, y = row - f * h;
+    const int x = c * 64 + lane;
+    const int v = x < w ? (int)img[(size_t)row * w + x] : -1;
+    const int ws = bit_row_words(w);
+    const size_t plane_words = (size_t)h * ws;
+    uint32_t *out = planes + (size_t)f * nplanes * plane_words + (size_t)y * ws;
+    unsigned long long mine = 0;
+    for (int t = 0; t < nplanes; t++) {
+        unsigned long long b = __ballot(v > thr0 + t * step);
+        if (lane == t) mine = b;
+    }
+    if (lane < nplanes) {
+        uint32_t *o = out + (size_t)lane * plane_words;
+        o[1 + 2 * c] = (uint32_t)mine;
+        o[2 + 2 * c] = (uint32_t)(mine >> 32);
+        if (c == 0) o[0] = 0;
+        if (c == chunks - 1) for (int k = 1 + 2 * chunks; k < ws; k++) o[k] = 0;
+    }
+}
+
 }  // namespace
+
+int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step, int nplanes, uint32_t *planes, hipStream_t s)
+{
+    CPE_CHECK_ARG(nplanes >= 1 && nplanes <= 64, "build_bitplanes: 1..64 planes");
+    const long long waves = (long long)n * h * ((w + 63) >> 6);
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_bitplanes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, img, n * h, h, w, thr0, step, nplanes, planes);
+    CPE_CHECK_LAUNCH("k_bitplanes");
+    return CPE_OK;
+}
 
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s)
 {

@@ -11,7 +11,6 @@ constexpr int MAXB = 4096;       // blobs per threshold
 constexpr int MAXG = 2048;       // blob groups (key-point candidates)
 constexpr int GCAP = 20;         // centres per group
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
-constexpr int MAXD = 262144;     // blob contour-distance scratch (double) per image and threshold
 constexpr int MAXL = 64;         // grid lines per direction
 constexpr int MAXLP = 64;        // points per grid line
 constexpr int MAXSEG = 2048;     // line fragments per mask in the expansion stage
@@ -62,7 +61,9 @@ struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
 struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
     int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
-    int2 *hl, *bl;   // per-threshold component lists of the blob sweep (dark / bright)
+    uint32_t *pool;   // border points of the hole traces (chunked)
+    uint32_t *bits;   // 17 one-bit planes per frame (threshold images), reused for single mask planes later
+    int2 *hl, *bl, *tl;   // per-threshold component lists of the blob sweep (dark / bright)
     unsigned int *hist;
     uint8_t *lut;
     BlobRec *blobs;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void uf_unite(int *L, int a, int b)
 // The 8 neighbours of the current pixel are fetched together (independent loads, one memory latency per
 // border step instead of one per examined neighbour); the direction search then runs on the bit mask.
 template <class Pred>
-__device__ __forceinline__ unsigned nbr_mask(const Pred &nz, int x, int y)
+__device__ __forceinline__ unsigned nbr_mask(Pred &nz, int x, int y)
 {
     const bool b0 = nz(x + 1, y), b1 = nz(x + 1, y - 1), b2 = nz(x, y - 1), b3 = nz(x - 1, y - 1);
     const bool b4 = nz(x - 1, y), b5 = nz(x - 1, y + 1), b6 = nz(x, y + 1), b7 = nz(x + 1, y + 1);
@@ -136,11 +137,64 @@ __device__ __forceinline__ unsigned nbr_mask(const Pred &nz, int x, int y)
            (b6 ? 64u : 0u) | (b7 ? 128u : 0u);
 }
 
+// 1-bit planes for border following.  A row is `bit_row_words(w)` u32 words; pixel x is bit (x + 32) of its row: one
+// zero word on the left and at least two on the right, so every 64-column window that starts on a word boundary is
+// one 8-byte load and never wraps into the next row.  BitWin keeps a 16-row x 64-column window around the current
+// border pixel in LDS (one column of `win` per lane): a border step costs three LDS reads, and global memory is
+// touched only when the border leaves the window (every ~10 steps) instead of eight dependent loads per step.
+constexpr int BW_ROWS = 16;
+__host__ __device__ inline int bit_row_words(int w) { return ((w + 31) >> 5) + 4; }
+typedef unsigned long long u64_a4 __attribute__((aligned(4)));
+struct BitWin {
+    const uint32_t *plane;       // this frame's plane
+    int ws, h;
+    unsigned long long *win;     // LDS, row r of this lane at win[r * 64]
+    int wx0 = 0, wy0 = INT_MIN / 2;   // padded bit index of window column 0, image row of window row 0
+    __device__ __forceinline__ void load(int x, int y)
+    {
+        const int k = (x + 16) >> 5;   // (x + 32 - 16) / 32: the pixel lands in columns 16..47 of the window
+        wx0 = 32 * k;
+        wy0 = y - BW_ROWS / 2;
+#pragma unroll
+        for (int r = 0; r < BW_ROWS; r++) {
+            const int yy = wy0 + r;
+            const int cy = min(max(yy, 0), h - 1);
+            unsigned long long v = *(const u64_a4 *)(plane + (size_t)cy * ws + k);
+            win[r * 64] = ((unsigned)yy < (unsigned)h) ? v : 0ull;
+        }
+    }
+    __device__ __forceinline__ unsigned nbrs(int x, int y)
+    {
+        int p = x + 32 - wx0, r = y - wy0;
+        if (p < 1 || p > 62 || r < 1 || r > BW_ROWS - 2) {
+            load(x, y);
+            p = x + 32 - wx0; r = y - wy0;
+        }
+        const unsigned ta = (unsigned)(win[(r - 1) * 64] >> (p - 1)) & 7u;   // bit 0: x - 1, bit 1: x, bit 2: x + 1
+        const unsigned tb = (unsigned)(win[r * 64] >> (p - 1)) & 7u;
+        const unsigned tc = (unsigned)(win[(r + 1) * 64] >> (p - 1)) & 7u;
+        return ((tb >> 2) & 1u) | (((ta >> 2) & 1u) << 1) | (((ta >> 1) & 1u) << 2) | ((ta & 1u) << 3) | ((tb & 1u) << 4) |
+               ((tc & 1u) << 5) | (((tc >> 1) & 1u) << 6) | (((tc >> 2) & 1u) << 7);
+    }
+    __device__ __forceinline__ bool operator()(int x, int y) const   // single pixel, straight from the plane
+    {
+        if ((unsigned)x >= (unsigned)(32 * (ws - 3)) || (unsigned)y >= (unsigned)h) return false;
+        return (plane[(size_t)y * ws + ((x + 32) >> 5)] >> ((x + 32) & 31)) & 1u;
+    }
+};
+__device__ __forceinline__ unsigned nbr_mask(BitWin &bw, int x, int y) { return bw.nbrs(x, y); }
+
+// planes[t] = (img > thr0 + t * step), t < nplanes; plane stride per frame = nplanes_alloc * h * bit_row_words(w)
+int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step, int nplanes, uint32_t *planes, hipStream_t s);
+
+// direction s = 0..7 counter-clockwise from east (x right, y down): DX = {1,1,0,-1,-1,-1,0,1}, DY = {0,-1,-1,-1,0,1,1,1},
+// stored as 2-bit fields (value + 1) so a step needs no table in memory
+__device__ __forceinline__ int trace_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
+__device__ __forceinline__ int trace_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
+
 template <class Pred, class Visitor>
-__device__ bool trace_border(const Pred &nz, int x0, int y0, bool is_hole, Visitor &vis, int max_steps)
+__device__ bool trace_border(Pred &nz, int x0, int y0, bool is_hole, Visitor &vis, int max_steps)
 {
-    const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-    const int DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
     int s, s_end;
     s_end = s = is_hole ? 0 : 4;
     unsigned bits = nbr_mask(nz, x0, y0);
@@ -151,16 +205,13 @@ __device__ bool trace_border(const Pred &nz, int x0, int y0, bool is_hole, Visit
         vis.point(x0, y0, true);
         return true;
     }
-    const int x1 = x0 + DX[s], y1 = y0 + DY[s];
+    const int x1 = x0 + trace_dx(s), y1 = y0 + trace_dy(s);
     int x3 = x0, y3 = y0, prev_s = s ^ 4;
     for (int step = 0; step < max_steps; step++) {
-        int k = 0;
-        for (;;) {
-            ++s;
-            if (((bits >> (s & 7)) & 1u) || ++k >= 16) break;
-        }
-        s &= 7;
-        const int x4 = x3 + DX[s], y4 = y3 + DY[s];
+        // first set neighbour counter-clockwise after s (the pixel we came from is always set, so one exists)
+        const unsigned rot = ((bits | (bits << 8)) >> ((s + 1) & 7)) & 0xFFu;
+        if (rot) s = (s + __ffs(rot)) & 7;
+        const int x4 = x3 + trace_dx(s), y4 = y3 + trace_dy(s);
         bool vertex = (s != prev_s);
         vis.point(x3, y3, vertex);
         if (vertex) prev_s = s;

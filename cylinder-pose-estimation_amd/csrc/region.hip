@@ -131,7 +131,7 @@ struct DistVisitor {
 
 // ---- threshold sweep bookkeeping: per-frame int counters (SW_STRIDE ints per frame)
 constexpr int NTHR = 17;          // thresholds 50, 60, ..., 210 (SimpleBlobDetector defaults, util_cylinder.py:1836)
-constexpr int SW_STRIDE = 160;
+constexpr int SW_STRIDE = 192;
 constexpr int NBK = NTHR + 1;     // grey-level buckets: 0: v <= 50, b: 50 + 10 (b - 1) < v <= 50 + 10 b, 17: v > 210
 enum {
     SW_NH = 8,                    // + k: dark components away from the rectangle border at threshold k (length of hl[k])
@@ -140,37 +140,77 @@ enum {
     SW_ND = SW_NB + NTHR,         // + k: border distances stored for threshold k
     SW_BS = SW_ND + NTHR,         // + b: pixels of bucket b inside the rectangle
     SW_BO = SW_BS + NBK,          // + b: first entry of bucket b in the bucket plane
-    SW_BC = SW_BO + NBK           // + b: fill cursor
+    SW_BC = SW_BO + NBK,          // + b: fill cursor
+    SW_NT = SW_BC + NBK,          // + k: holes of threshold k whose border is followed (length of tl[k])
+    SW_NC = SW_NT + NTHR          // + k: border-point chunks in use
 };
-static_assert(SW_BC + NBK <= SW_STRIDE, "sweep counters");
+static_assert(SW_NC + NTHR <= SW_STRIDE, "sweep counters");
 
 // one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
 // lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
-__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w, int is_hole,
+// Border points of the hole traces are kept while the border is followed the first time, in 128-byte chunks of a pool
+// per frame and threshold (word 0: previous chunk of the same border, words 1..31: x | y << 16), so the accepted blobs
+// need no second pass along their border; k_blob_median turns the points into distances.
+constexpr int CH_PTS = 31;
+constexpr int MAXCH = 8192;            // chunks per frame and threshold
+constexpr int MAXCHAIN = 512;          // chunks of one border the median kernel can index (15 872 points)
+constexpr int PTS_STORED = 0x40000000; // blob_d[2 bi] = last chunk | PTS_STORED, else offset into the distance scratch
+constexpr int MAXDF = 65536;           // distance scratch (double) per frame and threshold: bright blobs, fall-backs
+
+struct StoreVisitor {
+    StatVisitor sv;
+    uint32_t *pool;
+    int *counter;
+    int cur = -1, fill = CH_PTS;
+    bool ok = true;
+    __device__ __forceinline__ void point(int x, int y, bool vertex)
+    {
+        sv.point(x, y, vertex);
+        if (!ok) return;
+        if (fill == CH_PTS) {
+            const int c = (sv.npts <= MAXCHAIN * CH_PTS) ? atomicAdd(counter, 1) : MAXCH;
+            if (c >= MAXCH) { ok = false; return; }
+            pool[(size_t)c * 32] = (uint32_t)cur;
+            cur = c;
+            fill = 0;
+        }
+        pool[(size_t)cur * 32 + 1 + fill] = (uint32_t)x | ((uint32_t)y << 16);
+        fill++;
+    }
+    __device__ __forceinline__ bool stop() const { return false; }
+};
+
+template <int is_hole>
+__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w,
                                                    const int2 *__restrict__ lists, int cnt_base,
                                                    FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
-                                                   int *__restrict__ blob_d_all, double *__restrict__ dists_all)
+                                                   int *__restrict__ blob_d_all, double *__restrict__ dists_all,
+                                                   const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all)
 {
+    __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int f = blockIdx.y, slot = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int thr = 50 + 10 * slot;
     int *S = sw + (size_t)f * SW_STRIDE;
     if (k >= min(S[cnt_base + slot], MAXROOTS)) return;
-    const size_t N = (size_t)h * w;
     const int2 e = lists[((size_t)f * NTHR + slot) * MAXROOTS + k];
     const int root = e.x;
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
     if (e.y >= 5000) return;
     int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
-    double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXD;
+    double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXDF;
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
-    ThreshPred nz{cl + f * N, w, h, thr};
-    StatVisitor sv;
+    const int ws = bit_row_words(w);
+    BitWin nz{bits + ((size_t)f * NTHR + slot) * h * ws, ws, h, s_win + threadIdx.x};   // binarised = cl > 50 + 10 slot
     const int max_steps = 4 * (w + h) + 65536;
-    bool ok = trace_border(nz, x0, y0, is_hole != 0, sv, max_steps);
+    StoreVisitor tv;
+    tv.pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
+    tv.counter = &S[SW_NC + slot];
+    tv.ok = is_hole != 0;   // bright components: few are accepted, their borders are followed again instead
+    StatVisitor &sv = tv.sv;
+    bool ok = trace_border(nz, x0, y0, is_hole != 0, tv, max_steps);
     if (!ok) { st[f].overflow = 1; return; }
     sv.finish();
     double m00, m10, m01;
@@ -182,49 +222,95 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     if (nz(ix, iy)) return;  // blobColor = 0: centre pixel must be dark (out-of-image cannot happen for a valid centroid)
     int bi = atomicAdd(&S[SW_NB + slot], 1);
     if (bi >= MAXB) { st[f].overflow = 1; return; }
-    int doff = atomicAdd(&S[SW_ND + slot], sv.npts);
-    if (doff + sv.npts > MAXD) { st[f].overflow = 1; blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
-    else {
-        DistVisitor dv{cx, cy, dists + doff};
-        trace_border(nz, x0, y0, is_hole != 0, dv, max_steps);
-        blob_d[bi * 2] = doff;
+    if (tv.ok) {
+        blob_d[bi * 2] = tv.cur | PTS_STORED;
         blob_d[bi * 2 + 1] = sv.npts;
+    } else {
+        int doff = atomicAdd(&S[SW_ND + slot], sv.npts);
+        if (doff + sv.npts > MAXDF) { st[f].overflow = 1; blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
+        else {
+            DistVisitor dv{cx, cy, dists + doff};
+            trace_border(nz, x0, y0, is_hole != 0, dv, max_steps);
+            blob_d[bi * 2] = doff;
+            blob_d[bi * 2 + 1] = sv.npts;
+        }
     }
     BlobRec &b = blobs[bi];
     b.x = cx; b.y = cy; b.r = 0;
     b.key = root;   // discovery position of the border in the raster scan
 }
 
-// radius = (d[(n-1)/2] + d[n/2]) / 2 of the sorted border distances: one wavefront per blob
-__global__ __launch_bounds__(64) void k_blob_median(const int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
-                                                    const int *__restrict__ blob_d_all, const double *__restrict__ dists_all)
+// d[(n-1)/2] and d[n/2] of the sorted distances by rank counting (ties broken by index: every rank occurs once)
+template <class Ptr>
+__device__ __forceinline__ double median_of(Ptr d, int n, int lane)
 {
+    const int k1 = (n - 1) / 2, k2 = n / 2;
+    double v1 = 0, v2 = 0;
+    for (int i = lane; i < n; i += 64) {
+        double di = d[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            double dj = d[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        if (rank == k1) v1 = di;
+        if (rank == k2) v2 = di;
+    }
+    // exactly one lane holds each value
+    for (int off = 32; off >= 1; off >>= 1) {
+        v1 = fmax(v1, __shfl_xor(v1, off, 64));
+        v2 = fmax(v2, __shfl_xor(v2, off, 64));
+    }
+    return (v1 + v2) / 2.;
+}
+
+// radius = median distance of the border points from the centre: one wavefront per blob
+constexpr int MED_LDS = 1024;
+__global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
+                                                    const int *__restrict__ blob_d_all, double *__restrict__ dists_all,
+                                                    const uint32_t *__restrict__ pool_all, FrameState *__restrict__ st)
+{
+    __shared__ double s_d[MED_LDS];
+    __shared__ int s_ch[MAXCHAIN];
+    __shared__ int s_off;
     const int f = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
-    const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + slot], MAXB);
+    int *S = sw + (size_t)f * SW_STRIDE;
+    const int nb = min(S[SW_NB + slot], MAXB);
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
+    double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXDF;
+    const uint32_t *pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
     for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
-        int doff = blob_d[bi * 2], n = blob_d[bi * 2 + 1];
-        if (doff < 0 || n <= 0) continue;
-        const double *d = dists_all + ((size_t)f * NTHR + slot) * MAXD + doff;
-        const int k1 = (n - 1) / 2, k2 = n / 2;
-        double v1 = 0, v2 = 0;
-        for (int i = lane; i < n; i += 64) {
-            double di = d[i];
-            int rank = 0;
-            for (int j = 0; j < n; j++) {
-                double dj = d[j];
-                rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        const int code = blob_d[bi * 2], n = blob_d[bi * 2 + 1];
+        if (code < 0 || n <= 0) continue;
+        double r;
+        if (code & PTS_STORED) {
+            const int nch = (n + CH_PTS - 1) / CH_PTS;   // <= MAXCHAIN (StoreVisitor stops storing beyond that)
+            __syncthreads();
+            if (lane == 0) {
+                int c = code & (PTS_STORED - 1);
+                for (int j = nch - 1; j >= 0; j--) { s_ch[j] = c; c = (int)pool[(size_t)c * 32]; }
+                s_off = 0;
+                if (n > MED_LDS) s_off = atomicAdd(&S[SW_ND + slot], n);
             }
-            if (rank == k1) v1 = di;
-            if (rank == k2) v2 = di;
+            __syncthreads();
+            const double cx = blobs[bi].x, cy = blobs[bi].y;
+            const bool in_lds = n <= MED_LDS;
+            if (!in_lds && s_off + n > MAXDF) { if (lane == 0) st[f].overflow = 1; continue; }
+            double *out = dists + s_off;
+            for (int i = lane; i < n; i += 64) {
+                const uint32_t p = pool[(size_t)s_ch[i / CH_PTS] * 32 + 1 + i % CH_PTS];
+                const double dx = cx - (double)(int)(p & 0xFFFFu), dy = cy - (double)(int)(p >> 16);
+                const double v = sqrt(dx * dx + dy * dy);
+                if (in_lds) s_d[i] = v;
+                else out[i] = v;
+            }
+            __syncthreads();
+            r = in_lds ? median_of((const double *)s_d, n, lane) : median_of((const double *)out, n, lane);
+        } else {
+            r = median_of((const double *)(dists + code), n, lane);
         }
-        // exactly one lane holds each value
-        for (int off = 32; off >= 1; off >>= 1) {
-            v1 = fmax(v1, __shfl_xor(v1, off, 64));
-            v2 = fmax(v2, __shfl_xor(v2, off, 64));
-        }
-        if (lane == 0) blobs[bi].r = (v1 + v2) / 2.;
+        if (lane == 0) blobs[bi].r = r;
     }
 }
 
@@ -539,14 +625,32 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
 }
 
 // freeze the per-component totals of threshold slot `slot` next to the roots: the accumulator plane moves on
-__global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, const int *__restrict__ sw, int cnt_base, int slot,
-                                                 int h, int w, const int *__restrict__ acc)
+// trace (optional): the entries whose border has to be followed go to a dense list of their own, so the lanes of a
+// wavefront of k_blob_trace walk borders of similar length.  A hole of n <= 3 pixels spans at most 1x3 or 2x2 pixels,
+// its border polygon runs through pixels 8-adjacent to it, so its area is at most 2x4 or 3x3 < 10 = minArea;
+// a hole of n >= 5000 pixels has a border polygon of area >= n >= maxArea.
+__global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                                 int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= min(sw[f * SW_STRIDE + cnt_base + slot], MAXROOTS)) return;
-    int2 &e = lists[(f * NTHR + slot) * MAXROOTS + k];
-    e.y = acc[f * N + e.x];
+    const bool valid = k < min(sw[f * SW_STRIDE + cnt_base + slot], MAXROOTS);
+    int2 e = make_int2(0, 0);
+    if (valid) {
+        int2 &g = lists[(f * NTHR + slot) * MAXROOTS + k];
+        g.y = acc[f * N + g.x];
+        e = g;
+    }
+    if (!trace) return;
+    const bool want = valid && e.y > 3 && e.y < 5000;
+    const int lane = threadIdx.x & 63;
+    unsigned long long b = __ballot(want);
+    if (!b) return;
+    const int leader = __ffsll((long long)b) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
+    base = __shfl(base, leader, 64);
+    if (want) trace[(f * NTHR + slot) * MAXROOTS + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -818,11 +922,12 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k);
         }
-        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.hl, (const int *)B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt);
+        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
         CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
-    CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, 1, (const int2 *)B.hl, (int)SW_NH, st, B.sw, B.blobs,
-                B.blob_d, B.dists);
+    if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
+    CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
+                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool);
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
     for (int j = 0; j < NTHR; j++) {
@@ -837,12 +942,12 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, 0,
                         B.bl, B.sw, (int)SW_NL, k);
         CPE_KLAUNCH(k_enclosed, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
-        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.bl, (const int *)B.sw, (int)SW_NL, k, h, w, (const int *)B.cnt2);
+        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.bl, B.sw, (int)SW_NL, k, h, w, (const int *)B.cnt2, (int2 *)nullptr, st);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
-    CPE_KLAUNCH(k_blob_trace, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, 0, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
-                B.blob_d, B.dists);
-    CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, (const int *)B.sw, B.blobs, (const int *)B.blob_d, (const double *)B.dists);
+    CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
+                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool);
+    CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool, st);
     CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);

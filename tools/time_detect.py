@@ -24,3 +24,6 @@ cpe_amd.lib.profile(True)
 det = api.detect_grid_batch(frames, ws); torch.cuda.synchronize()
 rep = cpe_amd.lib.profile_report(); cpe_amd.lib.profile(False)
 print('event profile:', ' | '.join(f"{r[0].split('::')[-1]} x{r[1]} {r[2]:.1f}ms" for r in rep[:int(os.environ.get("CPE_TOP", "10"))]), "| total %.1f ms" % sum(r[2] for r in rep))
+if os.environ.get('CPE_DBG'):
+    stt = ws.state()
+    print('pad0 (max fg trace)', [s_['pad0'] for s_ in stt][:16], 'pad1 (max hole trace)', [s_['pad1'] for s_ in stt][:16], 'pad2 (sum)', [s_['pad2'] for s_ in stt][:16])
