@@ -315,68 +315,94 @@ __global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRe
 }
 
 // for every threshold in ascending order: order its blobs like cv2.findContours returns contours (latest discovery
-// first) and merge them into the groups (SimpleBlobDetector::detect inner loops); one wavefront per frame
-__global__ __launch_bounds__(64) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
-                                                   const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
-                                                   Group *__restrict__ groups)
+// first) and merge them into the groups (SimpleBlobDetector::detect inner loops); one workgroup per frame.
+// The loop over blobs is sequential by definition; what is parallel is the search over the groups (256 per step, their
+// middle centres live in LDS), the fetch of the next 64 blobs, and the sorted insertion (one lane per list element).
+__global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
+                                                    const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
+                                                    Group *__restrict__ groups)
 {
-    __shared__ double sMid[MAXG][3];   // location + radius of each group's middle centre (what the tests read)
-    const int f = blockIdx.x, lane = threadIdx.x;
+    // location + radius of each group's middle centre (what the tests read)
+    __shared__ double sX[MAXG], sY[MAXG], sR[MAXG];
+    __shared__ double bX[64], bY[64], bR[64];
+    __shared__ int s_jm;
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63;
     FrameState &S = st[f];
     int *ord = order + (size_t)f * MAXB;
     Group *G = groups + (size_t)f * MAXG;
     int ng = 0;
-    for (int t = 0; t < NTHR; t++) {
-        const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + t], MAXB);
-        const BlobRec *B = blobs_all + ((size_t)f * NTHR + t) * MAXB;
-        for (int i = lane; i < nb; i += 64) {
+    for (int thr = 0; thr < NTHR; thr++) {
+        const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + thr], MAXB);
+        const BlobRec *B = blobs_all + ((size_t)f * NTHR + thr) * MAXB;
+        for (int i = t; i < nb; i += 256) {
             int ki = B[i].key, rank = 0;
             for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0;
             ord[rank] = i;
         }
         __syncthreads();
         const int ng0 = ng;   // centres of this threshold are only compared with groups of the earlier ones
-        for (int q = 0; q < nb; q++) {
-            const BlobRec c = B[ord[q]];
-            int jm = INT_MAX;
-            for (int j0 = 0; j0 < ng0 && jm == INT_MAX; j0 += 64) {
-                int j = j0 + lane;
-                bool match = false;
-                if (j < ng0) {
-                    double dx = sMid[j][0] - c.x, dy = sMid[j][1] - c.y;
-                    double dist = sqrt(dx * dx + dy * dy);
-                    bool isNew = dist >= 10.0 && dist >= sMid[j][2] && dist >= c.r;
-                    match = !isNew;
-                }
-                unsigned long long bal = __ballot(match);
-                if (bal) jm = j0 + __ffsll((long long)bal) - 1;
-            }
-            if (lane == 0) {
-                if (jm != INT_MAX) {
-                    Group &g = G[jm];   // only lane 0 ever touches the group lists
-                    if (g.n < GCAP) {
-                        int k = g.n++;
-                        while (k > 0 && c.r < g.c[k - 1][2]) {
-                            g.c[k][0] = g.c[k - 1][0]; g.c[k][1] = g.c[k - 1][1]; g.c[k][2] = g.c[k - 1][2];
-                            k--;
-                        }
-                        g.c[k][0] = c.x; g.c[k][1] = c.y; g.c[k][2] = c.r;
-                        const double *mid = g.c[g.n / 2];
-                        sMid[jm][0] = mid[0]; sMid[jm][1] = mid[1]; sMid[jm][2] = mid[2];
-                    } else S.overflow = 1;
-                } else if (ng < MAXG) {
-                    Group &g = G[ng];
-                    g.n = 1;
-                    g.c[0][0] = c.x; g.c[0][1] = c.y; g.c[0][2] = c.r;
-                    sMid[ng][0] = c.x; sMid[ng][1] = c.y; sMid[ng][2] = c.r;
-                } else S.overflow = 1;
-            }
-            if (jm == INT_MAX && ng < MAXG) ng++;
+        for (int q0 = 0; q0 < nb; q0 += 64) {
+            if (t < 64 && q0 + t < nb) { const BlobRec &c = B[ord[q0 + t]]; bX[t] = c.x; bY[t] = c.y; bR[t] = c.r; }
+            if (t == 0) s_jm = INT_MAX;
             __syncthreads();
+            const int qn = min(64, nb - q0);
+            for (int qq = 0; qq < qn; qq++) {
+                const double cx = bX[qq], cy = bY[qq], cr = bR[qq];
+                int jmin = INT_MAX;
+                for (int j = t; j < ng0; j += 256) {
+                    const double dx = sX[j] - cx, dy = sY[j] - cy;
+                    const double d2 = dx * dx + dy * dy, rj = sR[j];
+                    // sqrt(d2) >= a certainly holds when d2 >= a * a * (1 + 2^-40): only the others need the root
+                    const double a = fmax(fmax(10.0, rj), cr);
+                    if (!(d2 >= a * a * 1.0000000000009095)) {
+                        const double dist = sqrt(d2);
+                        const bool isNew = dist >= 10.0 && dist >= rj && dist >= cr;
+                        if (!isNew) jmin = min(jmin, j);
+                    }
+                }
+                if (__ballot(jmin != INT_MAX)) {
+                    for (int off = 32; off >= 1; off >>= 1) jmin = min(jmin, __shfl_xor(jmin, off, 64));
+                    if (lane == 0) atomicMin(&s_jm, jmin);
+                }
+                __syncthreads();
+                const int jm = s_jm;
+                if (t < 64) {
+                    if (jm != INT_MAX) {
+                        Group &g = G[jm];
+                        const int gn = g.n;
+                        if (gn < GCAP) {
+                            // insertion behind the last centre whose radius is not larger (the list is sorted by radius)
+                            double ex = 0, ey = 0, er = 0;
+                            if (lane < GCAP) { ex = g.c[lane][0]; ey = g.c[lane][1]; er = g.c[lane][2]; }   // independent of the load of g.n
+                            const int pos = __popcll(__ballot(lane < gn && !(cr < er)));
+                            if (lane >= pos && lane < gn) { g.c[lane + 1][0] = ex; g.c[lane + 1][1] = ey; g.c[lane + 1][2] = er; }
+                            const int m = (gn + 1) / 2;
+                            const int src = m < pos ? m : m - 1;   // element of the old list that becomes the middle one
+                            double sx = __shfl(ex, src & 63, 64), sy = __shfl(ey, src & 63, 64), sr = __shfl(er, src & 63, 64);
+                            if (m == pos) { sx = cx; sy = cy; sr = cr; }
+                            if (lane == 0) {
+                                g.c[pos][0] = cx; g.c[pos][1] = cy; g.c[pos][2] = cr;
+                                g.n = gn + 1;
+                                sX[jm] = sx; sY[jm] = sy; sR[jm] = sr;
+                            }
+                        } else if (lane == 0) S.overflow = 1;
+                    } else if (ng < MAXG) {
+                        if (lane == 0) {
+                            Group &g = G[ng];
+                            g.n = 1;
+                            g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
+                            sX[ng] = cx; sY[ng] = cy; sR[ng] = cr;
+                        }
+                    } else if (lane == 0) S.overflow = 1;
+                    if (t == 0) s_jm = INT_MAX;
+                }
+                if (jm == INT_MAX && ng < MAXG) ng++;
+                __syncthreads();
+            }
         }
         __syncthreads();
     }
-    if (lane == 0) S.n_groups = ng;
+    if (t == 0) S.n_groups = ng;
 }
 
 // enclosed-hole pixel totals per bright component of threshold slot k:
@@ -948,7 +974,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool);
     CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool, st);
-    CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(64), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
+    CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(256), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
