@@ -78,6 +78,7 @@ struct MaskBuffers {
         *exp_v, *touch;
     uint16_t *tmp16;
     int *lab, *roots, *jtmp, *joints, *verts;
+    uint32_t *bits;
     unsigned long long *best;
     SegRec *segs;
 };

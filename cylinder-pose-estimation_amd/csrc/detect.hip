@@ -168,7 +168,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     M.joints_mask = PL(uint8_t, P_JOINTS_MASK); M.tmpA = PL(uint8_t, P_TMPA); M.tmpB = PL(uint8_t, P_TMPB);
     M.g19 = PL(uint8_t, P_G19); M.cm = PL(uint8_t, P_CM); M.mc = R.mc; M.roi_h = PL(uint8_t, P_ROI_H);
     M.roi_v = PL(uint8_t, P_ROI_V); M.base_h = PL(uint8_t, P_BASE_H); M.base_v = PL(uint8_t, P_BASE_V);
-    M.exp_h = PL(uint8_t, P_EXP_H); M.exp_v = PL(uint8_t, P_EXP_V); M.touch = R.touch; M.tmp16 = PL(uint16_t, P_TMP16);
+    M.exp_h = PL(uint8_t, P_EXP_H); M.exp_v = PL(uint8_t, P_EXP_V); M.touch = R.touch; M.bits = R.bits; M.tmp16 = PL(uint16_t, P_TMP16);
     M.lab = R.lab; M.roots = R.roots; M.jtmp = PL(int, P_JTMP); M.joints = PL(int, P_JOINTS); M.verts = PL(int, P_VERTS);
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
     int rc;

@@ -627,7 +627,7 @@ struct SegVisitor {
 };
 
 // one thread per fragment: CHAIN_APPROX_SIMPLE vertices (5..200) -> PCA end points, angle, length
-__global__ __launch_bounds__(64) void k_seg_trace(const uint8_t *__restrict__ base, int h, int w, int which,
+__global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ base_bits, int h, int w, int which,
                                                   const int *__restrict__ roots, FrameState *__restrict__ st,
                                                   SegRec *__restrict__ segs /* n*MAXSEG */)
 {
@@ -637,7 +637,9 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint8_t *__restrict__ ba
     if (k >= min(st[f].n_roots, MAXROOTS)) return;
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
-    MaskPred nz{base + f * N, w, h};
+    __shared__ unsigned long long s_win[BW_ROWS * 64];
+    const int ws = bit_row_words(w);
+    BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
     float pts[400];
     SegVisitor sv{pts};
     if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
@@ -875,7 +877,8 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
         uint8_t *base = which ? B.base_v : B.base_h;
         uint8_t *exp = which ? B.exp_v : B.exp_h;
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, base, h, w, which, B.roots, st,
+        if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, which, B.roots, st,
                            B.segs + (size_t)which * n * MAXSEG);
         CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, s, st, which, B.segs + (size_t)which * n * MAXSEG);
         (void)hipMemsetAsync(B.tmpB, 0, total, s);

@@ -719,16 +719,17 @@ __global__ __launch_bounds__(256) void k_discs(FrameState *__restrict__ st, cons
 }
 
 // contourArea of every external contour of the disc union; keep the largest (first in OpenCV order on ties)
-__global__ __launch_bounds__(64) void k_region_area(const uint8_t *__restrict__ ext, int h, int w,
+__global__ __launch_bounds__(64) void k_region_area(const uint32_t *__restrict__ ext_bits, int h, int w,
                                                     const int *__restrict__ roots, FrameState *__restrict__ st,
                                                     unsigned long long *__restrict__ best)
 {
+    __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= min(st[f].n_roots, MAXROOTS)) return;
-    const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
-    MaskPred nz{ext + f * N, w, h};
+    const int ws = bit_row_words(w);
+    BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
     StatVisitor sv;
     if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
     sv.finish();
@@ -785,7 +786,8 @@ __device__ void dev_line(uint8_t *img, int h, int w, int x1, int y1, int x2, int
 }
 
 // hull of the selected contour -> filled polygon (drawContours thickness=-1) + bounding rect
-__global__ __launch_bounds__(256) void k_hull_fill(const uint8_t *__restrict__ ext, int h, int w,
+constexpr int HULL_LDS_W = 2048;   // frames up to this width keep the column extents and the hull in LDS
+__global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ ext_bits, int h, int w,
                                                    const unsigned long long *__restrict__ best, FrameState *__restrict__ st,
                                                    int *__restrict__ lohi /* n * 2 * w */, int *__restrict__ hull /* n * 4 * w */,
                                                    uint8_t *__restrict__ mc)
@@ -799,12 +801,16 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint8_t *__restrict__ e
         return;
     }
     const int root = (int)(best[f] & 0xFFFFFF);
-    int *lo = lohi + (size_t)f * 2 * w, *hi = lo + w;
-    int *hp = hull + (size_t)f * 4 * w;
+    __shared__ int s_lo[HULL_LDS_W], s_hi[HULL_LDS_W], s_hp[4 * HULL_LDS_W];
+    __shared__ unsigned long long s_win[BW_ROWS * 64];
+    const bool in_lds = w <= HULL_LDS_W;
+    int *lo = in_lds ? s_lo : lohi + (size_t)f * 2 * w, *hi = in_lds ? s_hi : lohi + (size_t)f * 2 * w + w;
+    int *hp = in_lds ? s_hp : hull + (size_t)f * 4 * w;
     for (int x = t; x < w; x += 256) { lo[x] = INT_MAX; hi[x] = INT_MIN; }
     __syncthreads();
     if (t == 0) {
-        MaskPred nz{ext + f * N, w, h};
+        const int ws = bit_row_words(w);
+        BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win};
         HullVisitor hv{lo, hi};
         trace_border(nz, root % w, root / w, false, hv, 8 * (w + h) + (1 << 20));
         S.rect[0] = hv.minx; S.rect[1] = hv.miny; S.rect[2] = hv.maxx - hv.minx + 1; S.rect[3] = hv.maxy - hv.miny + 1;
@@ -980,8 +986,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     (void)hipMemsetAsync(B.mc, 0, total, s);
     CPE_KLAUNCH(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
     if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.ext, h, w, B.roots, st, B.best);
-    CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, B.ext, h, w, B.best, st, B.lohi, B.hull, B.mc);
+    if ((rc = build_bitplanes(B.ext, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
+    CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
+    CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
     return CPE_OK;
 }
