@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, in
 __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                     int invert, FrameState *__restrict__ st, int use_rect,
                                                     int *__restrict__ L, const uint8_t *__restrict__ touch, int count_mode,
-                                                    int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect, int sparse)
+                                                    int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect, int sparse,
+                                                    int noflatten)
 {
     // grid = (ceil(N / 256), n): a workgroup never straddles two frames, so every wave-level aggregate below is
     // per frame
@@ -149,7 +150,9 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
         const Rect r = get_rect(st, f, use_rect, h, w);
         if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) && (!sparse || pred(img + f * N, i, thr, invert))) {
             int v = L[gi];
-            if (v >= 0) {
+            if (noflatten) {
+                root = (v == i) ? i : -1;   // only the component list is wanted: a root is a root, flattened or not
+            } else if (v >= 0) {
                 root = uf_find_c(L + f * N, v);
                 L[gi] = root;
             }
@@ -334,8 +337,11 @@ int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int i
 // sparse 2: they are written as singletons (own raster index).
 // use_rect: restrict to st[].crect; nrect (optional, int[n][16]): accumulate the set's bounding box there.
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse)
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse, int flags)
 {
+    // flags: CCL_ROOTS_ONLY (1) = component list without flattening the label plane (needs roots, no counts / touch / bbox);
+    //        CCL_LINKS_ONLY (2) = stop after the unions: the consumer resolves the few labels it needs with uf_find
+    if (flags & 1) { CPE_CHECK_ARG(roots && !holes_only && !count_mode && !nrect, "ccl_run: roots-only pass with extra outputs"); }
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
     const unsigned gpx = (unsigned)((total + 255) / 256);
@@ -350,8 +356,9 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
         CPE_KLAUNCH(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const int *)L, n, h, w, (const FrameState *)st,
                     use_rect, touch);
     }
-    CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
-                holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse);
+    if (!(flags & 2))
+        CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
+                    holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;
 }

@@ -13,14 +13,14 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
-int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, int h, int w, const int *joints,
+int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
                 int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s);
 
@@ -179,10 +179,10 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
     if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
     if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
     if ((rc = blur7_u8(gray, n, h, w, M.tmp16, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
-    if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
+    if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                           n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
                           std::max(h, w) + 128, s)) != CPE_OK)
         return rc;

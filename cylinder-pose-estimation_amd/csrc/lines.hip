@@ -219,6 +219,7 @@ __device__ void sort_by_key(int *ord, int n, const double *key)
 }
 
 __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, const int *__restrict__ lab_v,
+                                               const uint8_t *__restrict__ exp_h, const uint8_t *__restrict__ exp_v,
                                                const uint8_t *__restrict__ g7, int h, int w,
                                                const int *__restrict__ joints, FrameState *__restrict__ st,
                                                LinesWS *__restrict__ wsall, double *__restrict__ o_xy,
@@ -237,7 +238,9 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     if (S.status != CPE_ST_OK) return;
     LinesWS &W = wsall[f];
     const size_t N = (size_t)h * w;
+    // union-find planes of the two expanded masks (unions done, not flattened): only the joints' labels are resolved
     const int *L[2] = {lab_h + f * N, lab_v + f * N};
+    const uint8_t *E[2] = {exp_h + f * N, exp_v + f * N};
     const int *J = joints + (size_t)f * MAXJ * 2;
     const int nj = min(S.n_joints, MAXJ);
     if (t == 0) s_ovf = 0;
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         for (int i = 0; i < nj; i++) {
             int jx = J[2 * i], jy = J[2 * i + 1];
             if (jx < 0 || jx >= w || jy < 0 || jy >= h) continue;
-            int lab = L[sd][(size_t)jy * w + jx];
-            if (lab < 0) continue;
+            if (!E[sd][(size_t)jy * w + jx]) continue;   // background label
+            int lab = uf_find(L[sd], jy * w + jx);
             int g = -1;
             for (int k = 0; k < ng; k++)
                 if (W.glabel[sd][k] == lab) { g = k; break; }
@@ -569,12 +572,12 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
 
 }  // namespace
 
-int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *g7, int n, int h, int w, const int *joints,
+int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
                 int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s)
 {
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
+    CPE_KLAUNCH(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, exp_h, exp_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
                        o_id, o_n, o_center, gray, subpixel, sp_window, sp_step, sp_scratch, sp_cap);
     CPE_CHECK_LAUNCH("k_lines");
     return CPE_OK;

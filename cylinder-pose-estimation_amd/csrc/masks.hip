@@ -12,7 +12,7 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 
 namespace {
@@ -852,14 +852,14 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
     // joints
-    if ((rc = ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots, st, B.jtmp);
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // spot
     Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
     CPE_KLAUNCH(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, gray, total, h, w, t19, B.tmp16);
     CPE_KLAUNCH(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, B.tmp16, total, h, w, t19, B.g19);
-    if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots, st, B.best);
     (void)hipMemsetAsync(B.cm, 255, total, s);
     CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best, st, B.verts, B.cm);
@@ -876,7 +876,7 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     for (int which = 0; which < 2; which++) {
         uint8_t *base = which ? B.base_v : B.base_h;
         uint8_t *exp = which ? B.exp_v : B.exp_h;
-        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s)) != CPE_OK) return rc;
+        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, which, B.roots, st,
                            B.segs + (size_t)which * n * MAXSEG);
