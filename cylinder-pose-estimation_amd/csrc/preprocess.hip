@@ -5,7 +5,7 @@
 // One workgroup (1024 threads = 16 waves, one per CU: the tile buffers take ~147 KB of the
 // 160 KB LDS) produces a 64x64 tile of the binary ridge mask.  Everything between the u8 frame
 // read and the u8 mask write lives in LDS:
-//   A  gray   (TY+46)x(TX+46) u8   halo 23 = 2 (blur5) + 12 (Gauss) + 2 (gradients) + 7 (box)
+//   A  gray   (TY+46)x(TX+48) u8   halo 23 = 2 (blur5) + 12 (Gauss) + 2 (gradients) + 7 (box), rows start 4-byte aligned
 //   B  blur5  (TY+42)x(TX+42) u8   integer, exact, BORDER_REFLECT_101; 0 outside the image
 //   C  V      (TY+18)x(TX+42) f64  Gaussian along y (scipy applies axis 0 first), zero padded
 //   D  G      (TY+18)x(TX+18) f64  Gaussian along x
@@ -21,7 +21,7 @@ namespace {
 
 constexpr int TX = 64, TY = 64, NT = 1024;
 constexpr int RA = 23, RB = 21, RG = 9, RE = 7;
-constexpr int AW = TX + 2 * RA, AH = TY + 2 * RA;   // 110
+constexpr int AW = TX + 2 * RA + 2, AH = TY + 2 * RA;   // 112 x 110: column 0 is x = gx0 - 24 (a 4-byte boundary)
 constexpr int BW = TX + 2 * RB, BH = TY + 2 * RB;   // 106
 constexpr int VW = BW, VH = TY + 2 * RG;            // 106 x 82
 constexpr int GW_ = TX + 2 * RG, GH = TY + 2 * RG;  // 82 x 82
@@ -35,7 +35,7 @@ __constant__ double c_gw[13] = {
     0x1.763a210dfb305p-15};
 
 struct Smem {
-    uint8_t a[AH * AW];
+    uint8_t a[AH * AW + 16];   // + slack: the last strip of phase B reads one dword past its row
     uint8_t b5[BH * BW];
     double buf1[VH * VW];  // V, later b
     double buf2[GH * GW_]; // G, later row sums
@@ -76,68 +76,128 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
     const uint8_t *img = gray + (size_t)frame * h * w;
     uint8_t *out = mask + (size_t)frame * h * w;
 
-    // A: gray with reflect-101 addressing
-    for (int i = tid; i < AH * AW; i += NT) {
-        int ry = i / AW, rx = i - ry * AW;
-        int y = cpe::reflect101(gy0 - RA + ry, h), x = cpe::reflect101(gx0 - RA + rx, w);
-        s.a[i] = img[(size_t)y * w + x];
+    // A: gray with reflect-101 addressing; LDS column j is x = gx0 - 24 + j.  Tiles whose window lies inside the
+    // frame (and whose rows are 4-byte aligned in memory) move dwords, the others single bytes.
+    {
+        const bool fast = ((w & 3) == 0) && ((((size_t)img) & 3) == 0) && gx0 - 24 >= 0 && gx0 - 24 + AW <= w &&
+                          gy0 - RA >= 0 && gy0 - RA + AH <= h;
+        if (fast) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (size_t)(gy0 - RA) * w + (gx0 - 24));
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s.a);
+            const int wq = w >> 2;
+            for (int i = tid; i < AH * (AW / 4); i += NT) {
+                int ry = i / (AW / 4), q = i - ry * (AW / 4);
+                dst[i] = src[(size_t)ry * wq + q];
+            }
+        } else {
+            for (int i = tid; i < AH * AW; i += NT) {
+                int ry = i / AW, rx = i - ry * AW;
+                int y = cpe::reflect101(gy0 - RA + ry, h), x = cpe::reflect101(gx0 - 24 + rx, w);
+                s.a[i] = img[(size_t)y * w + x];
+            }
+        }
     }
     __syncthreads();
 
-    // B: 5x5 binomial, exact integer: (sum + 128) >> 8 ; 0 outside the image
-    for (int i = tid; i < BH * BW; i += NT) {
-        int ry = i / BW, rx = i - ry * BW;
-        int y = gy0 - RB + ry, x = gx0 - RB + rx;
-        int v = 0;
-        if (y >= 0 && y < h && x >= 0 && x < w) {
-            const uint8_t *p = &s.a[ry * AW + rx];  // (ry+2-2, rx+2-2)
-            int acc = 0;
+    // B: 5x5 binomial, exact integer: (sum + 128) >> 8 ; 0 outside the image.
+    // b5 column rx (x = gx0 - 21 + rx) reads LDS columns rx + 1 .. rx + 5.  A thread makes the 8 outputs
+    // u0 .. u0 + 7 (u = rx + 1, u0 a multiple of 8) of one row from 5 x 3 aligned dwords.
+    {
+        constexpr int SB = (BW + 1 + 7) / 8;   // 14 strips per row
+        const uint32_t *a32 = reinterpret_cast<const uint32_t *>(s.a);
+        for (int i = tid; i < BH * SB; i += NT) {
+            const int ry = i / SB, u0 = (i - ry * SB) * 8;
+            const int y = gy0 - RB + ry;
+            int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int dy = 0; dy < 5; dy++) {
                 const int ky = (dy == 0 || dy == 4) ? 1 : ((dy == 2) ? 6 : 4);
-                const uint8_t *q = p + dy * AW;
-                acc += ky * (q[0] + 4 * q[1] + 6 * q[2] + 4 * q[3] + q[4]);
+                const uint32_t *q = a32 + ((ry + dy) * AW + u0) / 4;
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                int p[12];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    p[k] = (d0 >> (8 * k)) & 255; p[4 + k] = (d1 >> (8 * k)) & 255; p[8 + k] = (d2 >> (8 * k)) & 255;
+                }
+#pragma unroll
+                for (int o = 0; o < 8; o++) acc[o] += ky * (p[o] + 4 * p[o + 1] + 6 * p[o + 2] + 4 * p[o + 3] + p[o + 4]);
             }
-            v = (acc + 128) >> 8;
+            const bool yin = y >= 0 && y < h;
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                const int rx = u0 + o - 1;
+                if (rx >= 0 && rx < BW) {
+                    const int x = gx0 - RB + rx;
+                    s.b5[ry * BW + rx] = (uint8_t)((yin && x >= 0 && x < w) ? ((acc[o] + 128) >> 8) : 0);
+                }
+            }
         }
-        s.b5[i] = (uint8_t)v;
     }
     __syncthreads();
 
     const double inv255 = 1.0 / 255;
     // C: Gaussian along y.  V = 0 outside the image (the x pass zero-pads).
-    for (int i = tid; i < VH * VW; i += NT) {
-        int ry = i / VW, rx = i - ry * VW;
-        int y = gy0 - RG + ry, x = gx0 - RB + rx;
-        double tsum = 0.0;
-        if (y >= 0 && y < h && x >= 0 && x < w) {
-            const uint8_t *p = &s.b5[(ry + 12) * BW + rx];  // b5 row of global y
-            tsum = ((double)p[0] * inv255) * c_gw[0];
+    // One thread = KC consecutive rows of one column: the KC + 24 inputs are read (and converted) once into registers
+    // instead of 25 times; every output still adds its taps in scipy's order.
+    {
+        constexpr int KC = 10, GC = (VH + KC - 1) / KC;   // 9 row groups x 106 columns = 954 threads busy
+        static_assert(GC * VW <= NT, "phase C fits one round");
+        if (tid < GC * VW) {
+            const int grp = tid / VW, rx = tid - grp * VW;
+            const int ry0 = grp * KC;
+            const int x = gx0 - RB + rx;
+            double cv[KC + 24];
 #pragma unroll
-            for (int j = 12; j >= 1; j--) {
-                double a = (double)p[-j * BW] * inv255;
-                double b = (double)p[j * BW] * inv255;
-                double sm = a + b;
-                double pr = sm * c_gw[j];
-                tsum = tsum + pr;
+            for (int k = 0; k < KC + 24; k++) {
+                const int r = ry0 + k;
+                cv[k] = (r < BH) ? (double)s.b5[r * BW + rx] * inv255 : 0.0;
+            }
+#pragma unroll
+            for (int o = 0; o < KC; o++) {
+                const int ry = ry0 + o;
+                if (ry < VH) {
+                    const int y = gy0 - RG + ry;
+                    double tsum = 0.0;
+                    if (y >= 0 && y < h && x >= 0 && x < w) {
+                        tsum = cv[o + 12] * c_gw[0];
+#pragma unroll
+                        for (int j = 12; j >= 1; j--) {
+                            double sm = cv[o + 12 - j] + cv[o + 12 + j];
+                            double pr = sm * c_gw[j];
+                            tsum = tsum + pr;
+                        }
+                    }
+                    s.buf1[ry * VW + rx] = tsum;
+                }
             }
         }
-        s.buf1[i] = tsum;
     }
     __syncthreads();
 
-    // D: Gaussian along x
-    for (int i = tid; i < GH * GW_; i += NT) {
-        int ry = i / GW_, rx = i - ry * GW_;
-        const double *p = &s.buf1[ry * VW + rx + 12];
-        double tsum = p[0] * c_gw[0];
+    // D: Gaussian along x: one thread = KD consecutive columns of one row
+    {
+        constexpr int KD = 7, GD = (GW_ + KD - 1) / KD;   // 12 column groups x 82 rows = 984 threads busy
+        static_assert(GD * GH <= NT, "phase D fits one round");
+        if (tid < GD * GH) {
+            const int ry = tid / GD, grp = tid - ry * GD;
+            const int rx0 = grp * KD;
+            double cv[KD + 24];
 #pragma unroll
-        for (int j = 12; j >= 1; j--) {
-            double sm = p[-j] + p[j];
-            double pr = sm * c_gw[j];
-            tsum = tsum + pr;
+            for (int k = 0; k < KD + 24; k++) cv[k] = (rx0 + k < VW) ? s.buf1[ry * VW + rx0 + k] : 0.0;
+#pragma unroll
+            for (int o = 0; o < KD; o++) {
+                if (rx0 + o < GW_) {
+                    double tsum = cv[o + 12] * c_gw[0];
+#pragma unroll
+                    for (int j = 12; j >= 1; j--) {
+                        double sm = cv[o + 12 - j] + cv[o + 12 + j];
+                        double pr = sm * c_gw[j];
+                        tsum = tsum + pr;
+                    }
+                    s.buf2[ry * GW_ + rx0 + o] = tsum;
+                }
+            }
         }
-        s.buf2[i] = tsum;
     }
     __syncthreads();
 
@@ -174,54 +234,59 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
     }
     __syncthreads();
 
-    // F/G: 15x15 box of b and b*b (row sums left->right, then column sums top->bottom)
+    // F/G: 15x15 box of b and b*b (row sums left->right, then column sums top->bottom).  Register windows again:
+    // a thread makes KF neighbouring row sums from KF + 14 inputs, and the 4 column sums of its 4 output pixels
+    // (same column, consecutive rows) from 18 row sums.
     const double *bb = s.buf1;
     double *rs = s.buf2;
-    double mean[TX * TY / NT];
-    for (int i = tid; i < EH * TX; i += NT) {
-        int ry = i / TX, tx = i - ry * TX;
-        const double *p = &bb[ry * EW + tx];
-        double acc = 0.0;
+    constexpr int KF = 8, GF = TX / KF;   // 8 groups x 78 rows = 624 threads busy
+    constexpr int KG = TX * TY / NT;      // 4 output rows per thread
+    const int otx = tid % TX, oty0 = (tid / TX) * KG;
+    double mean[KG];
+    auto row_sums = [&](bool squared) {
+        if (tid < GF * EH) {
+            const int ry = tid / GF, tx0 = (tid - ry * GF) * KF;
+            double cv[KF + 14];
 #pragma unroll
-        for (int j = 0; j < 15; j++) acc = acc + p[j];
-        rs[i] = acc;
-    }
-    __syncthreads();
+            for (int k = 0; k < KF + 14; k++) {
+                double v = bb[ry * EW + tx0 + k];
+                cv[k] = squared ? v * v : v;
+            }
 #pragma unroll
-    for (int k = 0; k < TX * TY / NT; k++) {
-        int i = tid + k * NT;
-        int ty = i / TX, tx = i - ty * TX;
-        const double *p = &rs[ty * TX + tx];
-        double acc = 0.0;
+            for (int o = 0; o < KF; o++) {
+                double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 15; j++) acc = acc + p[j * TX];
-        mean[k] = acc * (1.0 / 225.0);
-    }
-    __syncthreads();
-    for (int i = tid; i < EH * TX; i += NT) {
-        int ry = i / TX, tx = i - ry * TX;
-        const double *p = &bb[ry * EW + tx];
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 15; j++) {
-            double v = p[j];
-            acc = acc + v * v;
+                for (int j = 0; j < 15; j++) acc = acc + cv[o + j];
+                rs[ry * TX + tx0 + o] = acc;
+            }
         }
-        rs[i] = acc;
-    }
+    };
+    auto col_sums = [&](double *res) {
+        double cv[KG + 14];
+#pragma unroll
+        for (int k = 0; k < KG + 14; k++) cv[k] = rs[(oty0 + k) * TX + otx];
+#pragma unroll
+        for (int o = 0; o < KG; o++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 15; j++) acc = acc + cv[o + j];
+            res[o] = acc * (1.0 / 225.0);
+        }
+    };
+    row_sums(false);
     __syncthreads();
+    col_sums(mean);
+    __syncthreads();
+    row_sums(true);
+    __syncthreads();
+    double mean_sq[KG];
+    col_sums(mean_sq);
 #pragma unroll
-    for (int k = 0; k < TX * TY / NT; k++) {
-        int i = tid + k * NT;
-        int ty = i / TX, tx = i - ty * TX;
-        int y = gy0 + ty, x = gx0 + tx;
-        const double *p = &rs[ty * TX + tx];
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 15; j++) acc = acc + p[j * TX];
-        double mean_sq = acc * (1.0 / 225.0);
-        double m = mean[k];
-        double var = mean_sq - m * m;
+    for (int o = 0; o < KG; o++) {
+        const int ty = oty0 + o, tx = otx;
+        const int y = gy0 + ty, x = gx0 + tx;
+        double m = mean[o];
+        double var = mean_sq[o] - m * m;
         if (var < 0) var = 0;
         double sd = sqrt(var);
         double T = m * (1 + 0.5 * ((sd / 128) - 1));
