@@ -26,15 +26,37 @@ import torch
 H, W = 1200, 1920
 BYTES_PER_FRAME = 2 * (H * W + 1024 * 24)          # 4 657 152 B per stereo frame
 HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/s HBM3E
-# algorithmic bytes per pixel of one launch (what the kernel must read + write once), DESIGN.md section 4
+# algorithmic bytes of one launch (what the kernel must read + write once), DESIGN.md section 4.
+#   streaming kernels: bytes per pixel of the frames (or of the blob detector's working rectangle) they walk;
+#   list kernels: bytes of the records they consume / produce, from the per-frame counters of the same run.
 ALGO_BYTES_PER_PX = {
     'k_preprocess': 2.0,        # u8 frame in, u8 mask out
-    'k_ccl_init': 5.0,          # u8 image in, i32 label out
-    'k_ccl_merge': 5.0,         # u8 image in, i32 labels read (unions touch few of them)
-    'k_ccl_finish': 9.0,        # u8 image + i32 labels in, i32 labels out
+    'k_ccl_init': 5.0,          # u8 image in, i32 label out (sparse passes write less)
+    'k_ccl_merge': 1.0,         # u8 image in; unions touch few labels
+    'k_ccl_finish': 5.0,        # u8 image + i32 labels of the set in
+    'k_roi_base': 5.0,          # three u8 masks in, two out
+    'k_open20_joints': 4.0,     # u8 mask in, three u8 masks out
+    'k_bitplanes': 1.0 + 17.0 / 8, 'k_bk_pass': 1.0,
     'k_morph_rect': 2.0,        # u8 in, u8 out
     'k_blur_h': 3.0, 'k_blur_v': 3.0, 'k_clahe_apply': 2.0, 'k_and2': 3.0, 'k_and3': 4.0, 'k_or_and': 4.0,
 }
+
+
+def list_kernel_bytes(short, ws, n_img):
+    """algorithmic bytes per launch of the kernels that walk component / blob lists (not pixels)"""
+    sw = ws.plane('sweep').cpu().numpy().astype(np.int64)
+    st = ws.state()
+    dark, bright, blobs = sw[:, 8:25].sum(), sw[:, 25:42].sum(), sw[:, 42:59].sum()
+    groups = sum(s_['n_groups'] for s_ in st)
+    if short == 'k_blob_merge':      # 32-B blob records in, 488-B group lists read + written once per touching blob
+        return blobs * (32 + 2 * 488)
+    if short == 'k_blob_median':     # ~160 border points of 4 B per blob in, radius out
+        return blobs * (160 * 4 + 8)
+    if short.startswith('k_blob_trace'):   # a border step reads 3 x 8 B of the bit window, stores a 4-B point
+        return blobs * 160 * 28
+    if short.startswith('k_sw_'):    # 4-B parent + 1-B level of every pixel that joins, a few neighbours each
+        return (dark + bright) * 8 * 5
+    return None
 
 
 def pmc_traffic(kernel, images_per_launch):
@@ -141,15 +163,17 @@ def main():
         name, calls, ms = rep[0]
         short = name.split('::')[-1]
         px_per_launch = 2 * c * H * W
+        short = short.split('<')[0]
         bpp = ALGO_BYTES_PER_PX.get(short)
-        if bpp is None:      # irregular kernel (border tracing ...): it has to see each frame's pixels at most once
-            bpp = 1.0
-        if short.startswith('k_ccl_'):
-            # 34 of the 41 labelling passes per image only work inside the blob detector's rectangle
-            st = pipe._ws(2 * c).state()
-            rect_px = float(np.mean([max(0, s_['crect2'] - s_['crect0'] + 1) * max(0, s_['crect3'] - s_['crect1'] + 1) for s_ in st]))
-            px_per_launch = 2 * c * (34 * rect_px + 7 * H * W) / 41
-        algo = bpp * px_per_launch
+        algo = None
+        if bpp is None:
+            algo = list_kernel_bytes(short, pipe._ws(2 * c), 2 * c)
+            if algo is not None:
+                algo = float(algo) / calls
+            else:            # other irregular kernels (border tracing ...): each frame's pixels at most once
+                bpp = 1.0
+        if algo is None:
+            algo = bpp * px_per_launch
         avg_s = ms / calls / 1e3
         roof = dict(bound='hbm', kernel=short, calls_per_chunk=calls, avg_launch_ms=ms / calls, share_of_gpu_time=ms / tot,
                     algorithmic_bytes_per_launch=algo, achieved=algo / avg_s / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',

@@ -15,7 +15,7 @@ from . import lib as _lib
 from .fit import GridTables, MAXP
 
 PLANES = dict(binary=0, hmask=1, vmask=2, mask_contour=3, roi_h=4, roi_v=5, exp_h=6, exp_v=7, joints=8, state=9,
-              clahe=10, blur19=11, blur7=12, labels=13)
+              clahe=10, blur19=11, blur7=12, labels=13, sweep=14)
 STATUS_TEXT = {0: 'ok', 1: 'no region (cv2.convexHull(None))', 2: 'no saturated spot (circle_radius0 unbound)',
                3: 'no valid rows/cols', 4: 'empty point list', 5: 'too few points', 6: 'workspace capacity exceeded',
                7: 'sub-pixel refinement raised (line sample above / left of the image)'}
@@ -48,7 +48,7 @@ class DetectWorkspace:
             return raw.view(torch.int32).reshape(self.n, -1, 2)
         if name == 'labels':
             return raw.view(torch.int32).reshape(self.n, self.h, self.w)
-        if name == 'state':
+        if name in ('state', 'sweep'):
             return raw.view(torch.int32).reshape(self.n, -1)
         return raw.reshape(self.n, self.h, self.w)
 

@@ -119,10 +119,11 @@ extern "C" size_t cpe_detect_workspace_bytes(int32_t n, int32_t h, int32_t w)
 extern "C" int32_t cpe_detect_workspace_plane(int32_t n, int32_t h, int32_t w, int32_t plane, size_t *offset,
                                               size_t *bytes_per_frame)
 {
-    CPE_CHECK_ARG(n > 0 && h > 0 && w > 0 && plane >= 0 && plane <= P_G7 + 1 && offset && bytes_per_frame,
+    CPE_CHECK_ARG(n > 0 && h > 0 && w > 0 && plane >= 0 && plane <= P_G7 + 2 && offset && bytes_per_frame,
                   "cpe_detect_workspace_plane: bad argument");
     Layout L = make_layout(n, h, w);
     if (plane == P_G7 + 1) plane = P_LAB0;
+    else if (plane == P_G7 + 2) plane = P_SW;
     *offset = L.off[plane];
     *bytes_per_frame = L.bytes_per_frame[plane];
     return CPE_OK;

@@ -119,6 +119,8 @@ CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t
 #define CPE_PLANE_CLAHE 10        /* u8[h,w]  CLAHE'd L channel */
 #define CPE_PLANE_BLUR19 11       /* u8[h,w] */
 #define CPE_PLANE_BLUR7 12        /* u8[h,w] */
+#define CPE_PLANE_SWEEP 14        /* i32[192] blob-sweep counters: [8+k] dark components, [25+k] bright components,
+                                     [42+k] blobs of threshold 50+10k (k < 17); see csrc/region.hip SW_* */
 CPE_API int32_t cpe_detect_workspace_plane(int32_t n, int32_t h, int32_t w, int32_t plane, size_t *offset,
                                            size_t *bytes_per_frame);
 
