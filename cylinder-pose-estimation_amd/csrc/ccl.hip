@@ -31,8 +31,11 @@ struct Rect { int x0, y0, x1, y1; };
 __device__ __forceinline__ Rect get_rect(const FrameState *st, size_t f, int use_rect, int h, int w)
 {
     Rect r;
-    if (use_rect) { r.x0 = st[f].crect[0]; r.y0 = st[f].crect[1]; r.x1 = st[f].crect[2]; r.y1 = st[f].crect[3]; }
-    else { r.x0 = 0; r.y0 = 0; r.x1 = w - 1; r.y1 = h - 1; }
+    if (use_rect == 1) { r.x0 = st[f].crect[0]; r.y0 = st[f].crect[1]; r.x1 = st[f].crect[2]; r.y1 = st[f].crect[3]; }
+    else if (use_rect == 2) {   // region rectangle (boundingRect of the hull) + 2 px: holds every mask derived from mask_contour
+        const int *q = st[f].rect;
+        r.x0 = max(q[0] - 2, 0); r.y0 = max(q[1] - 2, 0); r.x1 = min(q[0] + q[2] + 1, w - 1); r.y1 = min(q[1] + q[3] + 1, h - 1);
+    } else { r.x0 = 0; r.y0 = 0; r.x1 = w - 1; r.y1 = h - 1; }
     return r;
 }
 
@@ -74,32 +77,46 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_merge(const uint8_t *__restrict__ img, size_t total, int h, int w, int thr,
+// grid = (ceil(N / 1024), n): a thread owns 4 consecutive pixels (one dword of the image when rows allow), so the
+// common case -- none of them in the set -- costs one load and no 64-bit index arithmetic
+__global__ __launch_bounds__(256) void k_ccl_merge(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                    int invert, int conn8, const FrameState *__restrict__ st, int use_rect,
                                                    int *__restrict__ L)
 {
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total) return;
-    const size_t N = (size_t)h * w;
-    const size_t f = gi / N;
-    const int i = (int)(gi - f * N);
-    const int y = i / w, x = i - y * w;
+    const int N = h * w;
+    const size_t f = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= N) return;
     const Rect r = get_rect(st, f, use_rect, h, w);
-    if (y <= r.y0 || y > r.y1 || x < r.x0 || x > r.x1) return;
-    const uint8_t *im = img + f * N;
-    if (!pred(im, i, thr, invert)) return;
-    int *Lf = L + f * N;
-    const bool up = pred(im, i - w, thr, invert);
-    const bool left = x > r.x0 && pred(im, i - 1, thr, invert);
-    if (up) {
-        bool upleft = x > r.x0 && pred(im, i - w - 1, thr, invert);
-        if (!(left && upleft)) uf_unite(Lf, i, i - w);
-    } else if (conn8) {
-        if (x < r.x1 && pred(im, i - w + 1, thr, invert)) {
-            bool right = pred(im, i + 1, thr, invert);
-            if (!right) uf_unite(Lf, i, i - w + 1);
+    int y = i0 / w, x = i0 - y * w;
+    if (y > r.y1 || y + 1 < r.y0) return;
+    const uint8_t *im = img + f * (size_t)N;
+    if (((((size_t)im) | (size_t)N) & 3) == 0) {
+        const uint32_t v4 = *reinterpret_cast<const uint32_t *>(im + i0);
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) any |= ((((int)((v4 >> (8 * k)) & 255u) > thr) ? 1 : 0) != invert);
+        if (!any) return;
+    }
+    int *Lf = L + f * (size_t)N;
+    for (int k = 0; k < 4; k++, x++) {
+        const int i = i0 + k;
+        if (i >= N) break;
+        if (x == w) { x = 0; y++; }
+        if (y <= r.y0 || y > r.y1 || x < r.x0 || x > r.x1) continue;
+        if (!pred(im, i, thr, invert)) continue;
+        const bool up = pred(im, i - w, thr, invert);
+        const bool left = x > r.x0 && pred(im, i - 1, thr, invert);
+        if (up) {
+            bool upleft = x > r.x0 && pred(im, i - w - 1, thr, invert);
+            if (!(left && upleft)) uf_unite(Lf, i, i - w);
+        } else if (conn8) {
+            if (x < r.x1 && pred(im, i - w + 1, thr, invert)) {
+                bool right = pred(im, i + 1, thr, invert);
+                if (!right) uf_unite(Lf, i, i - w + 1);
+            }
+            if (x > r.x0 && !left && pred(im, i - w - 1, thr, invert)) uf_unite(Lf, i, i - w - 1);
         }
-        if (x > r.x0 && !left && pred(im, i - w - 1, thr, invert)) uf_unite(Lf, i, i - w - 1);
     }
 }
 
@@ -344,12 +361,12 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     if (flags & 1) { CPE_CHECK_ARG(roots && !holes_only && !count_mode && !nrect, "ccl_run: roots-only pass with extra outputs"); }
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
-    const unsigned gpx = (unsigned)((total + 255) / 256);
     CPE_LAUNCH_BEGIN();
     if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0);
     CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                 count_mode ? cnt : (int *)nullptr, sparse);
-    CPE_KLAUNCH(k_ccl_merge, dim3(gpx), dim3(256), 0, s, img, total, h, w, thr, invert, conn8, (const FrameState *)st, use_rect, L);
+    CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + 1023) / 1024), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
+                (const FrameState *)st, use_rect, L);
     if (holes_only) {
         (void)hipMemsetAsync(touch, 0, total, s);
         int per = 2 * w + 2 * h;

@@ -76,7 +76,6 @@ struct RegionBuffers {
 struct MaskBuffers {
     uint8_t *binary, *hmask, *vmask, *joints_mask, *tmpA, *tmpB, *g19, *cm, *mc, *roi_h, *roi_v, *base_h, *base_v, *exp_h,
         *exp_v, *touch;
-    uint16_t *tmp16;
     int *lab, *roots, *jtmp, *joints, *verts;
     uint32_t *bits;
     unsigned long long *best;

@@ -18,7 +18,7 @@ int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
-int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *dst, hipStream_t s);
+int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
@@ -48,7 +48,7 @@ Layout make_layout(int n, int h, int w)
     for (int i = 0; i < P_COUNT; i++) per[i] = N;  // u8 planes by default
     per[P_JOINTS] = (size_t)MAXJ * 2 * sizeof(int);
     per[P_STATE] = sizeof(FrameState);
-    per[P_TMP16] = N * 2;
+    per[P_TMP16] = 16;   // (unused)
     per[P_LAB0] = N * 4;
     per[P_LAB1] = N * 4;
     per[P_ROOTS] = (size_t)MAXROOTS * sizeof(int);
@@ -169,7 +169,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     M.joints_mask = PL(uint8_t, P_JOINTS_MASK); M.tmpA = PL(uint8_t, P_TMPA); M.tmpB = PL(uint8_t, P_TMPB);
     M.g19 = PL(uint8_t, P_G19); M.cm = PL(uint8_t, P_CM); M.mc = R.mc; M.roi_h = PL(uint8_t, P_ROI_H);
     M.roi_v = PL(uint8_t, P_ROI_V); M.base_h = PL(uint8_t, P_BASE_H); M.base_v = PL(uint8_t, P_BASE_V);
-    M.exp_h = PL(uint8_t, P_EXP_H); M.exp_v = PL(uint8_t, P_EXP_V); M.touch = R.touch; M.bits = R.bits; M.tmp16 = PL(uint16_t, P_TMP16);
+    M.exp_h = PL(uint8_t, P_EXP_H); M.exp_v = PL(uint8_t, P_EXP_V); M.touch = R.touch; M.bits = R.bits;
     M.lab = R.lab; M.roots = R.roots; M.jtmp = PL(int, P_JTMP); M.joints = PL(int, P_JOINTS); M.verts = PL(int, P_VERTS);
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
     int rc;
@@ -180,9 +180,9 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
     if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
     if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
-    if ((rc = blur7_u8(gray, n, h, w, M.tmp16, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
+    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
+    if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
     if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                           n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
                           std::max(h, w) + 128, s)) != CPE_OK)

@@ -129,7 +129,8 @@ constexpr int RT_X = 64, RT_Y = 32, RAP = 4;
 constexpr int RW = RT_X + 2 * RAP, RH = RT_Y + 2 * RAP;
 __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m, const uint8_t *__restrict__ cm,
                                                   const uint8_t *__restrict__ mc, int h, int w, int tiles_x, int tiles_y,
-                                                  uint8_t *__restrict__ roi, uint8_t *__restrict__ base)
+                                                  const FrameState *__restrict__ st, uint8_t *__restrict__ roi,
+                                                  uint8_t *__restrict__ base)
 {
     __shared__ uint8_t a[RH * RW], b[RH * RW];   // 0 / 1, 2 = outside the image
     const int t = threadIdx.x;
@@ -137,6 +138,20 @@ __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m,
     const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
     const int gx0 = (tt % tiles_x) * RT_X, gy0 = (tt / tiles_x) * RT_Y;
     const size_t N = (size_t)h * w;
+    {
+        // mask_contour is zero outside the region rectangle; opening cannot add pixels and closing stays inside the
+        // dilation, so both outputs are zero further than one pixel from the rectangle
+        const int *r = st[f].rect;
+        const bool nohull = st[f].status == CPE_ST_NO_REGION;
+        if (nohull || gx0 > r[0] + r[2] + 1 || gx0 + RT_X < r[0] - 1 || gy0 > r[1] + r[3] + 1 || gy0 + RT_Y < r[1] - 1) {
+            for (int i = t; i < RT_Y * RT_X; i += 256) {
+                int ry = i / RT_X, rx = i - ry * RT_X;
+                int y = gy0 + ry, x = gx0 + rx;
+                if (y < h && x < w) { roi[f * N + (size_t)y * w + x] = 0; base[f * N + (size_t)y * w + x] = 0; }
+            }
+            return;
+        }
+    }
     for (int i = t; i < RH * RW; i += 256) {
         int ry = i / RW, rx = i - ry * RW;
         int y = gy0 - RAP + ry, x = gx0 - RAP + rx;
@@ -233,33 +248,78 @@ __global__ __launch_bounds__(256) void k_joint_sort(FrameState *__restrict__ st,
 // ---- separable fixed-point Gaussian blur on u8 (cv2.GaussianBlur (7,7) and (19,19), sigma 0) ------------
 struct Taps { int k[19]; int r; int shift; };
 
-__global__ __launch_bounds__(256) void k_blur_h(const uint8_t *__restrict__ src, size_t total, int h, int w, Taps t,
-                                                uint16_t *__restrict__ tmp)
+// Both passes in one kernel: a 64x32 tile with an r-pixel apron goes through LDS, the u16 row sums never reach HBM.
+// Neither consumer needs the whole plane, so tiles that cannot matter are skipped:
+//   BLUR_SPOT (19x19): only `blurred > 240` is ever asked (util_cylinder.py:1958).  The taps sum to 2^16, so the
+//     result is <= the largest input: a tile whose apron holds no pixel > 240 is written as 0.
+//   BLUR_RECT (7x7): only the box means around the intersection points are read (find_center_point, :1548-1560), and
+//     those points lie inside the region rectangle: tiles away from rect +- (half + 1) are left untouched.
+constexpr int BT_X = 64, BT_Y = 32;
+enum { BLUR_SPOT = 0, BLUR_RECT = 1 };
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void k_blur_fused(const uint8_t *__restrict__ src, int h, int w, int tiles_x, int tiles_y, Taps t,
+                                                    const FrameState *__restrict__ st, uint8_t *__restrict__ dst)
 {
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total) return;
+    constexpr int IW = BT_X + 2 * R, IH = BT_Y + 2 * R;
+    __shared__ uint8_t s_in[IH * IW];
+    __shared__ uint16_t s_h[IH * BT_X];
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
+    const int gx0 = (tt % tiles_x) * BT_X, gy0 = (tt / tiles_x) * BT_Y;
     const size_t N = (size_t)h * w;
-    const size_t f = gi / N;
-    const int i = (int)(gi - f * N);
-    const int y = i / w, x = i - y * w;
-    const uint8_t *row = src + f * N + (size_t)y * w;
-    int s = 0;
-    for (int j = -t.r; j <= t.r; j++) s += t.k[j + t.r] * row[reflect101(x + j, w)];
-    tmp[gi] = (uint16_t)s;
-}
-__global__ __launch_bounds__(256) void k_blur_v(const uint16_t *__restrict__ tmp, size_t total, int h, int w, Taps t,
-                                                uint8_t *__restrict__ dst)
-{
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total) return;
-    const size_t N = (size_t)h * w;
-    const size_t f = gi / N;
-    const int i = (int)(gi - f * N);
-    const int y = i / w, x = i - y * w;
-    const uint16_t *im = tmp + f * N;
-    int s = 0;
-    for (int j = -t.r; j <= t.r; j++) s += t.k[j + t.r] * (int)im[(size_t)reflect101(y + j, h) * w + x];
-    dst[gi] = (uint8_t)((s + (1 << (t.shift - 1))) >> t.shift);
+    if (MODE == BLUR_RECT) {
+        const FrameState &S = st[f];
+        if (S.status != CPE_ST_OK) return;
+        int half = (int)(S.r0 / 5.0);
+        if (half < 3) half = 3;
+        if (half > 10) half = half + 5;
+        const int m = half + 1;
+        if (gx0 > S.rect[0] + S.rect[2] + m || gx0 + BT_X < S.rect[0] - m || gy0 > S.rect[1] + S.rect[3] + m ||
+            gy0 + BT_Y < S.rect[1] - m)
+            return;
+    }
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    const uint8_t *im = src + f * N;
+    int mx = 0;
+    for (int i = tid; i < IH * IW; i += 256) {
+        int ry = i / IW, rx = i - ry * IW;
+        int v = im[(size_t)reflect101(gy0 - R + ry, h) * w + reflect101(gx0 - R + rx, w)];
+        s_in[i] = (uint8_t)v;
+        mx = max(mx, v);
+    }
+    if (MODE == BLUR_SPOT) {
+        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    if (MODE == BLUR_SPOT && s_max <= 240) {
+        for (int i = tid; i < BT_Y * BT_X; i += 256) {
+            int ry = i / BT_X, rx = i - ry * BT_X;
+            if (gy0 + ry < h && gx0 + rx < w) dst[f * N + (size_t)(gy0 + ry) * w + gx0 + rx] = 0;
+        }
+        return;
+    }
+    for (int i = tid; i < IH * BT_X; i += 256) {
+        int ry = i / BT_X, rx = i - ry * BT_X;
+        const uint8_t *p = &s_in[ry * IW + rx];
+        int sacc = 0;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; j++) sacc += t.k[j] * p[j];
+        s_h[i] = (uint16_t)sacc;
+    }
+    __syncthreads();
+    for (int i = tid; i < BT_Y * BT_X; i += 256) {
+        int ry = i / BT_X, rx = i - ry * BT_X;
+        const uint16_t *p = &s_h[ry * BT_X + rx];
+        int sacc = 0;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; j++) sacc += t.k[j] * (int)p[j * BT_X];
+        if (gy0 + ry < h && gx0 + rx < w)
+            dst[f * N + (size_t)(gy0 + ry) * w + gx0 + rx] = (uint8_t)((sacc + (1 << (t.shift - 1))) >> t.shift);
+    }
 }
 
 // ---- saturated spot -> minEnclosingCircle -> ellipse erased from a 255 plane -----------------------
@@ -820,13 +880,14 @@ inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
 
 
 // cv2.GaussianBlur(img,(7,7),0) for indexing_data (util_cylinder.py:1433)
-int blur7_u8(const uint8_t *src, int n, int h, int w, uint16_t *tmp16, uint8_t *dst, hipStream_t s)
+int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s)
 {
     const size_t total = (size_t)h * w * n;
     Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, src, total, h, w, t7, tmp16);
-    CPE_KLAUNCH(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, tmp16, total, h, w, t7, dst);
+    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
+    CPE_KLAUNCH((k_blur_fused<3, BLUR_RECT>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, src, h, w, tiles_x, tiles_y, t7,
+                st, dst);
     CPE_CHECK_LAUNCH("blur7_u8");
     return CPE_OK;
 }
@@ -857,8 +918,11 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // spot
     Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
-    CPE_KLAUNCH(k_blur_h, dim3(grid1(total)), dim3(256), 0, s, gray, total, h, w, t19, B.tmp16);
-    CPE_KLAUNCH(k_blur_v, dim3(grid1(total)), dim3(256), 0, s, B.tmp16, total, h, w, t19, B.g19);
+    {
+        const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
+        CPE_KLAUNCH((k_blur_fused<9, BLUR_SPOT>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, gray, h, w, tiles_x, tiles_y,
+                    t19, (const FrameState *)st, B.g19);
+    }
     if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots, st, B.best);
     (void)hipMemsetAsync(B.cm, 255, total, s);
@@ -867,16 +931,16 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     {
         const int tiles_x = (w + RT_X - 1) / RT_X, tiles_y = (h + RT_Y - 1) / RT_Y;
         CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.hmask,
-                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, B.roi_h, B.base_h);
+                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, (const FrameState *)st, B.roi_h, B.base_h);
         CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.vmask,
-                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, B.roi_v, B.base_v);
+                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, (const FrameState *)st, B.roi_v, B.base_v);
     }
     CPE_CHECK_LAUNCH("masks_stage spot");
     // expansion
     for (int which = 0; which < 2; which++) {
         uint8_t *base = which ? B.base_v : B.base_h;
         uint8_t *exp = which ? B.exp_v : B.exp_h;
-        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
+        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, which, B.roots, st,
                            B.segs + (size_t)which * n * MAXSEG);
