@@ -62,6 +62,7 @@ struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
     int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
     uint32_t *pool;   // border points of the hole traces (chunked)
+    unsigned short *blob_ch;   // first 16 chunk ids of every blob's border
     uint32_t *bits;   // 17 one-bit planes per frame (threshold images), reused for single mask planes later
     int2 *hl, *bl, *tl;   // per-threshold component lists of the blob sweep (dark / bright)
     unsigned int *hist;

@@ -156,12 +156,15 @@ constexpr int MAXCH = 8192;            // chunks per frame and threshold
 constexpr int MAXCHAIN = 512;          // chunks of one border the median kernel can index (15 872 points)
 constexpr int PTS_STORED = 0x40000000; // blob_d[2 bi] = last chunk | PTS_STORED, else offset into the distance scratch
 constexpr int MAXDF = 65536;           // distance scratch (double) per frame and threshold: bright blobs, fall-backs
+constexpr int CH_DIRECT = 16;          // chunk ids kept with the blob record: borders up to 496 points need no chain walk
+static_assert(MAXCH <= 65536, "chunk ids are stored as u16");
 
 struct StoreVisitor {
     StatVisitor sv;
     uint32_t *pool;
     int *counter;
-    int cur = -1, fill = CH_PTS;
+    unsigned short *ids;   // LDS, entry j of this lane at ids[j * 64]: the first CH_DIRECT chunks of the border
+    int cur = -1, fill = CH_PTS, nch = 0;
     bool ok = true;
     __device__ __forceinline__ void point(int x, int y, bool vertex)
     {
@@ -173,6 +176,8 @@ struct StoreVisitor {
             pool[(size_t)c * 32] = (uint32_t)cur;
             cur = c;
             fill = 0;
+            if (nch < CH_DIRECT) ids[nch * 64] = (unsigned short)c;
+            nch++;
         }
         pool[(size_t)cur * 32 + 1 + fill] = (uint32_t)x | ((uint32_t)y << 16);
         fill++;
@@ -185,9 +190,11 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
                                                    const int2 *__restrict__ lists, int cnt_base,
                                                    FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
                                                    int *__restrict__ blob_d_all, double *__restrict__ dists_all,
-                                                   const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all)
+                                                   const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all,
+                                                   unsigned short *__restrict__ blob_ch_all)
 {
     __shared__ unsigned long long s_win[BW_ROWS * 64];
+    __shared__ unsigned short s_ids[CH_DIRECT * 64];
     const int f = blockIdx.y, slot = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     int *S = sw + (size_t)f * SW_STRIDE;
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     StoreVisitor tv;
     tv.pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
     tv.counter = &S[SW_NC + slot];
+    tv.ids = s_ids + threadIdx.x;
     tv.ok = is_hole != 0;   // bright components: few are accepted, their borders are followed again instead
     StatVisitor &sv = tv.sv;
     bool ok = trace_border(nz, x0, y0, is_hole != 0, tv, max_steps);
@@ -225,6 +233,8 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     if (tv.ok) {
         blob_d[bi * 2] = tv.cur | PTS_STORED;
         blob_d[bi * 2 + 1] = sv.npts;
+        unsigned short *ch = blob_ch_all + (((size_t)f * NTHR + slot) * MAXB + bi) * CH_DIRECT;
+        for (int j = 0; j < min(tv.nch, CH_DIRECT); j++) ch[j] = s_ids[j * 64 + threadIdx.x];
     } else {
         int doff = atomicAdd(&S[SW_ND + slot], sv.npts);
         if (doff + sv.npts > MAXDF) { st[f].overflow = 1; blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
@@ -264,15 +274,22 @@ __device__ __forceinline__ double median_of(Ptr d, int n, int lane)
     return (v1 + v2) / 2.;
 }
 
-// radius = median distance of the border points from the centre: one wavefront per blob
+// radius = median distance of the border points from the centre: one wavefront per blob.
+// The square root is monotone, so the two middle distances are the roots of the two middle squared distances.
+// Common case (border of up to 496 points, ids of its chunks in the blob record): the squared distances stay in
+// registers, a 64-bucket histogram over [min, max] (monotone bucket map) finds the bucket that holds rank k, and only
+// that bucket's few members are compared with each other -- O(n) instead of the O(n^2) rank count of the general path.
 constexpr int MED_LDS = 1024;
+constexpr int MED_FAST = CH_DIRECT * CH_PTS;
 __global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
                                                     const int *__restrict__ blob_d_all, double *__restrict__ dists_all,
-                                                    const uint32_t *__restrict__ pool_all, FrameState *__restrict__ st)
+                                                    const uint32_t *__restrict__ pool_all,
+                                                    const unsigned short *__restrict__ blob_ch_all, FrameState *__restrict__ st)
 {
     __shared__ double s_d[MED_LDS];
     __shared__ int s_ch[MAXCHAIN];
-    __shared__ int s_off;
+    __shared__ int s_hist[64];
+    __shared__ int s_off, s_cnt;
     const int f = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
     int *S = sw + (size_t)f * SW_STRIDE;
     const int nb = min(S[SW_NB + slot], MAXB);
@@ -280,11 +297,73 @@ __global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRe
     const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
     double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXDF;
     const uint32_t *pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
+    const unsigned short *blob_ch = blob_ch_all + ((size_t)f * NTHR + slot) * MAXB * CH_DIRECT;
     for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
         const int code = blob_d[bi * 2], n = blob_d[bi * 2 + 1];
         if (code < 0 || n <= 0) continue;
         double r;
-        if (code & PTS_STORED) {
+        if ((code & PTS_STORED) && n <= MED_FAST) {
+            const double cx = blobs[bi].x, cy = blobs[bi].y;
+            const int myid = lane < CH_DIRECT ? (int)blob_ch[bi * CH_DIRECT + lane] : 0;
+            double v[MED_FAST / 64 + 1];
+            double mn = 1e300, mx = -1.0;
+#pragma unroll
+            for (int m = 0; m < MED_FAST / 64 + 1; m++) {
+                const int i = lane + 64 * m;
+                const bool valid = i < n;
+                const int c = __shfl(myid, valid ? i / CH_PTS : 0, 64);
+                v[m] = -1.0;
+                if (valid) {
+                    const uint32_t p = pool[(size_t)c * 32 + 1 + i % CH_PTS];
+                    const double dx = cx - (double)(int)(p & 0xFFFFu), dy = cy - (double)(int)(p >> 16);
+                    v[m] = dx * dx + dy * dy;
+                    mn = fmin(mn, v[m]); mx = fmax(mx, v[m]);
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1) { mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64)); }
+            double res[2] = {mn, mn};
+            if (mx > mn) {
+                const double scale = 64.0 / (mx - mn);
+                int bkt[MED_FAST / 64 + 1];
+                __syncthreads();
+                s_hist[lane] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < MED_FAST / 64 + 1; m++) {
+                    bkt[m] = -1;
+                    if (v[m] >= 0.0) { bkt[m] = min(63, (int)((v[m] - mn) * scale)); atomicAdd(&s_hist[bkt[m]], 1); }
+                }
+                __syncthreads();
+                const int hc = s_hist[lane];
+                int incl = hc;
+                for (int off = 1; off < 64; off <<= 1) { int tt = __shfl_up(incl, off, 64); if (lane >= off) incl += tt; }
+                const int ks[2] = {(n - 1) / 2, n / 2};
+                for (int which = 0; which < 2; which++) {
+                    if (which == 1 && ks[1] == ks[0]) { res[1] = res[0]; break; }
+                    const int k = ks[which];
+                    const int bstar = __popcll(__ballot(incl <= k));          // first bucket whose running count exceeds k
+                    const int kk = k - __shfl(incl - hc, bstar, 64);          // rank inside that bucket
+                    const int sz = __shfl(hc, bstar, 64);
+                    __syncthreads();
+                    if (lane == 0) s_cnt = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (int m = 0; m < MED_FAST / 64 + 1; m++)
+                        if (bkt[m] == bstar) s_d[atomicAdd(&s_cnt, 1)] = v[m];
+                    __syncthreads();
+                    double found = -1.0;
+                    for (int j = lane; j < sz; j += 64) {
+                        const double x = s_d[j];
+                        int less = 0, leq = 0;
+                        for (int q = 0; q < sz; q++) { const double y = s_d[q]; less += (y < x) ? 1 : 0; leq += (y <= x) ? 1 : 0; }
+                        if (less <= kk && kk < leq) found = x;
+                    }
+                    for (int off = 32; off >= 1; off >>= 1) found = fmax(found, __shfl_xor(found, off, 64));
+                    res[which] = found;
+                }
+            }
+            r = (sqrt(res[0]) + sqrt(res[1])) / 2.;
+        } else if (code & PTS_STORED) {
             const int nch = (n + CH_PTS - 1) / CH_PTS;   // <= MAXCHAIN (StoreVisitor stops storing beyond that)
             __syncthreads();
             if (lane == 0) {
@@ -301,9 +380,9 @@ __global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRe
             for (int i = lane; i < n; i += 64) {
                 const uint32_t p = pool[(size_t)s_ch[i / CH_PTS] * 32 + 1 + i % CH_PTS];
                 const double dx = cx - (double)(int)(p & 0xFFFFu), dy = cy - (double)(int)(p >> 16);
-                const double v = sqrt(dx * dx + dy * dy);
-                if (in_lds) s_d[i] = v;
-                else out[i] = v;
+                const double vv = sqrt(dx * dx + dy * dy);
+                if (in_lds) s_d[i] = vv;
+                else out[i] = vv;
             }
             __syncthreads();
             r = in_lds ? median_of((const double *)s_d, n, lane) : median_of((const double *)out, n, lane);
@@ -316,8 +395,35 @@ __global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRe
 
 // for every threshold in ascending order: order its blobs like cv2.findContours returns contours (latest discovery
 // first) and merge them into the groups (SimpleBlobDetector::detect inner loops); one workgroup per frame.
-// The loop over blobs is sequential by definition; what is parallel is the search over the groups (256 per step, their
-// middle centres live in LDS), the fetch of the next 64 blobs, and the sorted insertion (one lane per list element).
+//
+// The merge is sequential by definition (a centre joins the FIRST group whose middle centre is close, and joining
+// moves that middle centre), so it is run in batches of 64 blobs:
+//   1. all threads: first matching group of every blob of the batch against the middle centres as they are at the
+//      start of the batch (LDS), no barrier between blobs;
+//   2. the centre lists of the groups found are fetched from HBM together (one round trip per batch);
+//   3. one wavefront replays the batch in order.  Only groups changed earlier in the batch can alter a blob's answer:
+//      if its group is unchanged, the changed groups with a smaller index are re-tested; if its group was changed, the
+//      blob is searched again.  Insertions work on the LDS copies (one lane per list element);
+//   4. changed lists go back to HBM.
+// Result and order of operations per blob are those of the sequential loop.
+__device__ __forceinline__ bool blob_joins(double gx, double gy, double gr, double cx, double cy, double cr)
+{
+    const double dx = gx - cx, dy = gy - cy;
+    const double d2 = dx * dx + dy * dy;
+    // sqrt(d2) >= a certainly holds when d2 >= a * a * (1 + 2^-40): only the others need the root
+    const double a = fmax(fmax(10.0, gr), cr);
+    if (d2 >= a * a * 1.0000000000009095) return false;
+    const double dist = sqrt(d2);
+    const bool isNew = dist >= 10.0 && dist >= gr && dist >= cr;
+    return !isNew;
+}
+
+__device__ __forceinline__ int wave_min_int(int v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
                                                     const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
                                                     Group *__restrict__ groups)
@@ -325,7 +431,9 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
     // location + radius of each group's middle centre (what the tests read)
     __shared__ double sX[MAXG], sY[MAXG], sR[MAXG];
     __shared__ double bX[64], bY[64], bR[64];
-    __shared__ int s_jm;
+    __shared__ double pl[64][GCAP * 3];   // centre lists of the groups the batch touches
+    __shared__ int pn[64], pg[64], pd[64], s_jm[64], s_mod[64];
+    __shared__ int s_ng, s_serial;
     const int f = blockIdx.x, t = threadIdx.x, lane = t & 63;
     FrameState &S = st[f];
     int *ord = order + (size_t)f * MAXB;
@@ -342,48 +450,160 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
         __syncthreads();
         const int ng0 = ng;   // centres of this threshold are only compared with groups of the earlier ones
         for (int q0 = 0; q0 < nb; q0 += 64) {
-            if (t < 64 && q0 + t < nb) { const BlobRec &c = B[ord[q0 + t]]; bX[t] = c.x; bY[t] = c.y; bR[t] = c.r; }
-            if (t == 0) s_jm = INT_MAX;
-            __syncthreads();
             const int qn = min(64, nb - q0);
-            for (int qq = 0; qq < qn; qq++) {
-                const double cx = bX[qq], cy = bY[qq], cr = bR[qq];
-                int jmin = INT_MAX;
-                for (int j = t; j < ng0; j += 256) {
-                    const double dx = sX[j] - cx, dy = sY[j] - cy;
-                    const double d2 = dx * dx + dy * dy, rj = sR[j];
-                    // sqrt(d2) >= a certainly holds when d2 >= a * a * (1 + 2^-40): only the others need the root
-                    const double a = fmax(fmax(10.0, rj), cr);
-                    if (!(d2 >= a * a * 1.0000000000009095)) {
-                        const double dist = sqrt(d2);
-                        const bool isNew = dist >= 10.0 && dist >= rj && dist >= cr;
-                        if (!isNew) jmin = min(jmin, j);
-                    }
+            if (t < 64) {
+                if (t < qn) { const BlobRec &c = B[ord[q0 + t]]; bX[t] = c.x; bY[t] = c.y; bR[t] = c.r; }
+                s_jm[t] = INT_MAX; pg[t] = -1; pd[t] = 0;
+            }
+            __syncthreads();
+            // 1. first match against the state at the start of the batch: lane = blob, each wavefront walks a quarter
+            //    of the groups (their centres are LDS broadcasts)
+            {
+                const int per = (ng0 + 3) / 4, jlo = (t >> 6) * per, jhi = min(jlo + per, ng0);
+                const bool act = lane < qn;
+                const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
+                int first = act ? INT_MAX : -1;
+                for (int j = jlo; j < jhi; j++) {
+                    if (first == INT_MAX && blob_joins(sX[j], sY[j], sR[j], cx, cy, cr)) first = j;
+                    if ((j & 15) == 15 && !__ballot(first == INT_MAX)) break;
                 }
-                if (__ballot(jmin != INT_MAX)) {
-                    for (int off = 32; off >= 1; off >>= 1) jmin = min(jmin, __shfl_xor(jmin, off, 64));
-                    if (lane == 0) atomicMin(&s_jm, jmin);
+                if (act && first != INT_MAX) atomicMin(&s_jm[lane], first);
+            }
+            __syncthreads();
+            // 2. one LDS slot per distinct group (slot = first blob of the batch that found it), filled together
+            if (t < 64) {
+                const int g = t < qn ? s_jm[t] : INT_MAX;
+                bool first = g != INT_MAX;
+                for (int dd = 0; dd < 64; dd++) {
+                    const int o = __shfl(g, dd, 64);
+                    if (dd < t && o == g) first = false;
                 }
-                __syncthreads();
-                const int jm = s_jm;
-                if (t < 64) {
+                if (first) pg[t] = g;
+            }
+            __syncthreads();
+            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += 256) {
+                const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
+                const int g = pg[q];
+                if (g >= 0) {
+                    if (e == GCAP * 3) pn[q] = G[g].n;
+                    else pl[q][e] = G[g].c[e / 3][e % 3];
+                }
+            }
+            __syncthreads();
+            // 3. Blobs of one batch rarely interact: if no two of them found the same group, and no group's new middle
+            //    centre draws in a later blob of the batch (tested pairwise, lane = blob), every lane inserts its own
+            //    blob at once.  Otherwise the batch is replayed in order by the code below (one wavefront; LDS
+            //    operations of a wavefront execute in order).
+            if (t < 64) {
+                const bool act = lane < qn;
+                const int jm = act ? s_jm[lane] : INT_MAX;
+                const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
+                bool dup = false;
+                for (int dd = 0; dd < 64; dd++) {
+                    const int o = __shfl(jm, dd, 64);
+                    if (dd != lane && o == jm && jm != INT_MAX) dup = true;
+                }
+                bool serial = __ballot(dup) != 0ull;
+                int gn = 0, pos = 0;
+                bool ins = false, full = false;
+                double nx = 0, ny = 0, nr = 0;
+                if (!serial) {
                     if (jm != INT_MAX) {
+                        gn = pn[lane];   // unique group: its slot is this blob's own
+                        full = gn >= GCAP;
+                        ins = !full;
+                        if (ins) {
+                            for (int k = 0; k < gn; k++) pos += !(cr < pl[lane][3 * k + 2]) ? 1 : 0;
+                            const int m = (gn + 1) / 2, src = m < pos ? m : m - 1;
+                            if (m == pos) { nx = cx; ny = cy; nr = cr; }
+                            else { nx = pl[lane][3 * src]; ny = pl[lane][3 * src + 1]; nr = pl[lane][3 * src + 2]; }
+                        }
+                    }
+                    // would an earlier blob's group, with its new middle centre, take this blob first?
+                    bool hit = false;
+                    for (int dd = 0; dd < 64; dd++) {
+                        const int og = __shfl(ins ? jm : -1, dd, 64);
+                        const double ox = __shfl(nx, dd, 64), oy = __shfl(ny, dd, 64), orr = __shfl(nr, dd, 64);
+                        if (dd < lane && act && og >= 0 && og < jm && blob_joins(ox, oy, orr, cx, cy, cr)) hit = true;
+                    }
+                    serial = __ballot(hit) != 0ull;
+                }
+                if (!serial) {
+                    if (ins) {
+                        for (int k = gn - 1; k >= pos; k--) {
+                            pl[lane][3 * k + 3] = pl[lane][3 * k]; pl[lane][3 * k + 4] = pl[lane][3 * k + 1]; pl[lane][3 * k + 5] = pl[lane][3 * k + 2];
+                        }
+                        pl[lane][3 * pos] = cx; pl[lane][3 * pos + 1] = cy; pl[lane][3 * pos + 2] = cr;
+                        pn[lane] = gn + 1; pd[lane] = 1;
+                        sX[jm] = nx; sY[jm] = ny; sR[jm] = nr;
+                    }
+                    if (full) S.overflow = 1;
+                    const bool fresh = act && jm == INT_MAX;
+                    const unsigned long long fb = __ballot(fresh);
+                    const int gi = ng + __popcll(fb & ((1ull << lane) - 1ull));
+                    if (fresh) {
+                        if (gi < MAXG) {
+                            Group &g = G[gi];
+                            g.n = 1;
+                            g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
+                            sX[gi] = cx; sY[gi] = cy; sR[gi] = cr;
+                        } else S.overflow = 1;
+                    }
+                    ng = min(ng + __popcll(fb), MAXG);
+                    if (t == 0) s_ng = ng;
+                }
+                if (t == 0) s_serial = serial ? 1 : 0;
+            }
+            __syncthreads();
+            if (t < 64 && s_serial) {
+                int nm = 0;
+                for (int q = 0; q < qn; q++) {
+                    const double cx = bX[q], cy = bY[q], cr = bR[q];
+                    int jm = s_jm[q];
+                    const int mj = lane < nm ? s_mod[lane] : -1;
+                    const bool changed = jm != INT_MAX && __ballot(mj == jm) != 0ull;
+                    if (changed) {
+                        int jmin = INT_MAX;
+                        for (int j = lane; j < ng0; j += 64)
+                            if (blob_joins(sX[j], sY[j], sR[j], cx, cy, cr)) jmin = min(jmin, j);
+                        jm = wave_min_int(jmin);
+                    } else {
+                        int cand = INT_MAX;
+                        if (mj >= 0 && mj < jm && blob_joins(sX[mj], sY[mj], sR[mj], cx, cy, cr)) cand = mj;
+                        jm = min(jm, wave_min_int(cand));
+                    }
+                    if (jm != INT_MAX) {
+                        const unsigned long long sb = __ballot(pg[lane] == jm);
+                        const int slot = sb ? __ffsll((long long)sb) - 1 : -1;
                         Group &g = G[jm];
-                        const int gn = g.n;
+                        const int gn = slot >= 0 ? pn[slot] : g.n;
                         if (gn < GCAP) {
                             // insertion behind the last centre whose radius is not larger (the list is sorted by radius)
                             double ex = 0, ey = 0, er = 0;
-                            if (lane < GCAP) { ex = g.c[lane][0]; ey = g.c[lane][1]; er = g.c[lane][2]; }   // independent of the load of g.n
+                            if (lane < GCAP) {
+                                if (slot >= 0) { ex = pl[slot][3 * lane]; ey = pl[slot][3 * lane + 1]; er = pl[slot][3 * lane + 2]; }
+                                else { ex = g.c[lane][0]; ey = g.c[lane][1]; er = g.c[lane][2]; }
+                            }
                             const int pos = __popcll(__ballot(lane < gn && !(cr < er)));
-                            if (lane >= pos && lane < gn) { g.c[lane + 1][0] = ex; g.c[lane + 1][1] = ey; g.c[lane + 1][2] = er; }
                             const int m = (gn + 1) / 2;
                             const int src = m < pos ? m : m - 1;   // element of the old list that becomes the middle one
                             double sx = __shfl(ex, src & 63, 64), sy = __shfl(ey, src & 63, 64), sr = __shfl(er, src & 63, 64);
                             if (m == pos) { sx = cx; sy = cy; sr = cr; }
-                            if (lane == 0) {
-                                g.c[pos][0] = cx; g.c[pos][1] = cy; g.c[pos][2] = cr;
-                                g.n = gn + 1;
-                                sX[jm] = sx; sY[jm] = sy; sR[jm] = sr;
+                            __builtin_amdgcn_wave_barrier();   // all lanes hold their element: now overwrite (LDS ops of a wave are in order)
+                            if (slot >= 0) {
+                                if (lane >= pos && lane < gn) { pl[slot][3 * lane + 3] = ex; pl[slot][3 * lane + 4] = ey; pl[slot][3 * lane + 5] = er; }
+                                if (lane == 0) {
+                                    pl[slot][3 * pos] = cx; pl[slot][3 * pos + 1] = cy; pl[slot][3 * pos + 2] = cr;
+                                    pn[slot] = gn + 1; pd[slot] = 1;
+                                }
+                            } else {
+                                if (lane >= pos && lane < gn) { g.c[lane + 1][0] = ex; g.c[lane + 1][1] = ey; g.c[lane + 1][2] = er; }
+                                if (lane == 0) { g.c[pos][0] = cx; g.c[pos][1] = cy; g.c[pos][2] = cr; g.n = gn + 1; }
+                            }
+                            if (lane == 0) { sX[jm] = sx; sY[jm] = sy; sR[jm] = sr; }
+                            if (__ballot(mj == jm) == 0ull) {   // first change of this group in the batch
+                                if (lane == 0) s_mod[nm] = jm;
+                                nm++;
                             }
                         } else if (lane == 0) S.overflow = 1;
                     } else if (ng < MAXG) {
@@ -393,12 +613,24 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
                             g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
                             sX[ng] = cx; sY[ng] = cy; sR[ng] = cr;
                         }
+                        ng++;
                     } else if (lane == 0) S.overflow = 1;
-                    if (t == 0) s_jm = INT_MAX;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                if (jm == INT_MAX && ng < MAXG) ng++;
-                __syncthreads();
+                if (t == 0) s_ng = ng;
             }
+            __syncthreads();
+            ng = s_ng;
+            // 4. changed lists back to HBM
+            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += 256) {
+                const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
+                const int g = pg[q];
+                if (g >= 0 && pd[q]) {
+                    if (e == GCAP * 3) G[g].n = pn[q];
+                    else if (e < pn[q] * 3) G[g].c[e / 3][e % 3] = pl[q][e];
+                }
+            }
+            __syncthreads();
         }
         __syncthreads();
     }
@@ -959,7 +1191,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     }
     if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
-                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool);
+                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
     for (int j = 0; j < NTHR; j++) {
@@ -978,8 +1210,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
-                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool);
-    CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool, st);
+                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
+    CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
+                (const unsigned short *)B.blob_ch, st);
     CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(256), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
