@@ -153,12 +153,17 @@ def main():
     # ---- per-kernel hipEvent timers on one more (untimed) pass over one chunk: the dominant kernel's roofline
     roof = None
     if rank == 0:
+        # (the timed region overlaps three independent chains on three streams; for per-kernel durations the chains
+        #  are put back on one stream, so a launch is timed alone on the GPU as rocprofv3 --kernel-trace would see it
+        #  in a serial run)
+        os.environ['CPE_SERIAL'] = '1'
         cpe_amd.lib.profile(True)
         c = min(args.chunk, F)
         pipe.run_chunk(left[:c], right[:c])
         torch.cuda.synchronize()
         rep = cpe_amd.lib.profile_report()
         cpe_amd.lib.profile(False)
+        os.environ.pop('CPE_SERIAL', None)
         tot = sum(r[2] for r in rep)
         name, calls, ms = rep[0]
         short = name.split('::')[-1]

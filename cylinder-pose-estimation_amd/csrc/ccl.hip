@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
                                                     int invert, FrameState *__restrict__ st, int use_rect,
                                                     int *__restrict__ L, const uint8_t *__restrict__ touch, int count_mode,
                                                     int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect, int sparse,
-                                                    int noflatten)
+                                                    int noflatten, int cnt_sel)
 {
     // grid = (ceil(N / 256), n): a workgroup never straddles two frames, so every wave-level aggregate below is
     // per frame
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
         if (rb) {
             int base = 0;
             const int leader = __ffsll((long long)rb) - 1;
-            if (lane == leader) base = atomicAdd(&st[f].n_roots, __popcll(rb));
+            if (lane == leader) base = atomicAdd(root_counter(st[f], cnt_sel), __popcll(rb));
             base = __shfl(base, leader, 64);
             if (is_root) {
                 int k = base + __popcll(rb & ((1ull << lane) - 1ull));
@@ -269,14 +269,14 @@ __global__ __launch_bounds__(256) void k_set_bbox(const uint8_t *__restrict__ im
     }
 }
 
-__global__ void k_ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op)
+__global__ void k_ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, int cnt_sel)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     FrameState &S = st[f];
     int *nr = nrect ? nrect + 16 * f : nullptr;
     if (op == 0) {          // reset the root list
-        S.n_roots = 0;
+        *root_counter(S, cnt_sel) = 0;
     } else if (op == 1) {   // working rectangle = whole frame, accumulator empty
         S.crect[0] = 0; S.crect[1] = 0; S.crect[2] = w - 1; S.crect[3] = h - 1;
         nr[0] = INT_MAX; nr[1] = INT_MAX; nr[2] = -1; nr[3] = -1;
@@ -331,7 +331,7 @@ int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step,
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s)
 {
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, op);
+    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, op, 0);
     CPE_CHECK_LAUNCH("k_ccl_ctl");
     return CPE_OK;
 }
@@ -341,9 +341,9 @@ int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int i
 {
     const size_t N = (size_t)h * w;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, 1);
+    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, 1, 0);
     CPE_KLAUNCH(k_set_bbox, dim3((unsigned)((N + 4095) / 4096), n), dim3(256), 0, s, img, h, w, thr, invert, nrect);
-    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, 2);
+    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, 2, 0);
     CPE_CHECK_LAUNCH("ccl_set_rect_to_bbox");
     return CPE_OK;
 }
@@ -354,7 +354,7 @@ int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int i
 // sparse 2: they are written as singletons (own raster index).
 // use_rect: restrict to st[].crect; nrect (optional, int[n][16]): accumulate the set's bounding box there.
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse, int flags)
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse, int flags, int cnt_sel)
 {
     // flags: CCL_ROOTS_ONLY (1) = component list without flattening the label plane (needs roots, no counts / touch / bbox);
     //        CCL_LINKS_ONLY (2) = stop after the unions: the consumer resolves the few labels it needs with uf_find
@@ -362,7 +362,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     const size_t N = (size_t)h * w, total = N * n;
     const int rows = n * h;
     CPE_LAUNCH_BEGIN();
-    if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0);
+    if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0, cnt_sel);
     CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                 count_mode ? cnt : (int *)nullptr, sparse);
     CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + 1023) / 1024), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
@@ -375,7 +375,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     }
     if (!(flags & 2))
         CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
-                    holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1);
+                    holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1, cnt_sel);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;
 }

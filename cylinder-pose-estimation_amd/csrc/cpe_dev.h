@@ -52,7 +52,9 @@ struct FrameState {
     int hull_n;
     int crect[4];       // working rectangle of a restricted labelling pass (x0, y0, x1, y1)
     int nrect[4];       // bounding-box accumulator
-    int pad[3];
+    int n_roots_p;      // component count of the joints labelling (runs on its own stream, beside the region stage)
+    int n_roots_s;      // component count of the spot labelling (third stream)
+    int spot_fail;      // the spot chain found no saturated spot: folded into `status` when the chains join
 };
 
 struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
@@ -78,10 +80,17 @@ struct MaskBuffers {
     uint8_t *binary, *hmask, *vmask, *joints_mask, *tmpA, *tmpB, *g19, *cm, *mc, *roi_h, *roi_v, *base_h, *base_v, *exp_h,
         *exp_v, *touch;
     int *lab, *roots, *jtmp, *joints, *verts;
+    int *lab_p, *roots_p, *lab_s, *roots_s;   // label planes / component lists of the joints and spot chains
     uint32_t *bits;
-    unsigned long long *best;
+    unsigned long long *best, *best_s;
     SegRec *segs;
 };
+
+// which per-frame component counter a labelling pass fills: 0 the main chain, 1 joints chain, 2 spot chain
+__device__ __forceinline__ int *root_counter(FrameState &S, int sel)
+{
+    return sel == 0 ? &S.n_roots : (sel == 1 ? &S.n_roots_p : &S.n_roots_s);
+}
 
 // ---------------------------------------------------------------- union-find on an int label plane
 __device__ __forceinline__ int uf_load(const int *L, int i)

@@ -8,15 +8,18 @@
 // caller-supplied workspace (cpe_detect_workspace_bytes), laid out plane-major so that every kernel
 // streams [n, h, w] planes with fully coalesced accesses.
 #include "cpe_dev.h"
+#include <mutex>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0, int cnt_sel = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
-int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s);
+int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
+int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
@@ -35,7 +38,7 @@ struct Layout {
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_COUNT
 };
 
 static_assert(P_COUNT <= 64, "Layout arrays too small");
@@ -74,6 +77,11 @@ Layout make_layout(int n, int h, int w)
     per[P_SW] = 192 * sizeof(int);
     per[P_TL] = (size_t)17 * MAXROOTS * sizeof(int2);
     per[P_BK] = N * 4;
+    per[P_LABP] = N * 4;
+    per[P_LABS] = N * 4;
+    per[P_ROOTSP] = (size_t)MAXROOTS * sizeof(int);
+    per[P_ROOTSS] = (size_t)MAXROOTS * sizeof(int);
+    per[P_BEST2] = sizeof(unsigned long long);
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);
     per[P_HL] = (size_t)17 * MAXROOTS * sizeof(int2);
     per[P_BL] = (size_t)17 * MAXROOTS * sizeof(int2);
@@ -104,6 +112,35 @@ __global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
     if (st[f].overflow) s = CPE_ST_OVERFLOW;
     status[f] = s;
     if (s != CPE_ST_OK) n_pts[f] = 0;
+}
+
+// two helper streams per process (created on first use; CPE_SERIAL=1 keeps everything on the caller's stream)
+struct SideStreams {
+    bool ok = false;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr;
+};
+SideStreams &side_streams()
+{
+    static SideStreams per_dev[32];
+    static std::mutex mu;
+    static SideStreams none;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return none;
+    const char *e = getenv("CPE_SERIAL");   // looked at on every call: a profiling pass can switch the overlap off
+    if (e && e[0] == '1') return none;
+    std::lock_guard<std::mutex> lk(mu);
+    SideStreams &X = per_dev[dev];
+    if (!X.s1 && !X.ok) {
+        bool good = hipStreamCreateWithFlags(&X.s1, hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&X.s2, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.join1, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.join2, hipEventDisableTiming) == hipSuccess;
+        X.ok = good;
+        if (!good) (void)hipGetLastError();
+    }
+    return X;
 }
 
 }  // namespace
@@ -173,13 +210,32 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     M.exp_h = PL(uint8_t, P_EXP_H); M.exp_v = PL(uint8_t, P_EXP_V); M.touch = R.touch; M.bits = R.bits;
     M.lab = R.lab; M.roots = R.roots; M.jtmp = PL(int, P_JTMP); M.joints = PL(int, P_JOINTS); M.verts = PL(int, P_VERTS);
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
+    M.lab_p = PL(int, P_LABP); M.lab_s = PL(int, P_LABS); M.roots_p = PL(int, P_ROOTSP); M.roots_s = PL(int, P_ROOTSS);
+    M.best_s = PL(unsigned long long, P_BEST2);
     int rc;
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
     CPE_CHECK_LAUNCH("k_state_init");
-    if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, stream)) != CPE_OK) return rc;
-    if ((rc = joints_mask_stage(n, h, w, M, s)) != CPE_OK) return rc;
+    // three chains that only meet in masks_stage: ridge mask -> line masks -> joints (stream 1), saturated spot
+    // (stream 2), region (the caller's stream).  The side chains are mostly ALU / latency bound and fill the CUs the
+    // region stage's serial kernels leave idle.
+    SideStreams &X = side_streams();
+    if (X.ok) {
+        (void)hipEventRecord(X.fork, s);
+        (void)hipStreamWaitEvent(X.s1, X.fork, 0);
+        (void)hipStreamWaitEvent(X.s2, X.fork, 0);
+    }
+    hipStream_t s1 = X.ok ? X.s1 : s, s2 = X.ok ? X.s2 : s;
+    if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
+    if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
+    if ((rc = spot_stage(gray, n, h, w, M, st, s2)) != CPE_OK) return rc;
     if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
+    if (X.ok) {
+        (void)hipEventRecord(X.join1, X.s1);
+        (void)hipEventRecord(X.join2, X.s2);
+        (void)hipStreamWaitEvent(s, X.join1, 0);
+        (void)hipStreamWaitEvent(s, X.join2, 0);
+    }
     if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
     if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
     if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 2)) != CPE_OK) return rc;

@@ -12,7 +12,7 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0, int cnt_sel = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 
 namespace {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restric
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (st[f].status != CPE_ST_OK) return;
-    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    if (k >= min(st[f].n_roots_p, MAXROOTS)) return;
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
     MaskPred nz{jm + f * N, w, h};
@@ -329,8 +329,7 @@ __global__ __launch_bounds__(64) void k_spot_area(const uint8_t *__restrict__ g1
 {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (st[f].status != CPE_ST_OK) return;
-    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    if (k >= min(st[f].n_roots_s, MAXROOTS)) return;   // (runs beside the region stage: no look at st[].status here)
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
     ThreshPred nz{g19 + f * N, w, h, 240};
@@ -603,8 +602,7 @@ __global__ __launch_bounds__(64) void k_spot_ellipse(const uint8_t *__restrict__
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     FrameState &S = st[f];
-    if (S.status != CPE_ST_OK) return;
-    if (best[f] == 0) { S.status = CPE_ST_NO_SPOT; return; }
+    if (best[f] == 0) { S.spot_fail = 1; return; }
     const size_t N = (size_t)h * w;
     const int root = (int)(best[f] & 0xFFFFFF);
     ThreshPred nz{g19 + f * N, w, h, 240};
@@ -865,13 +863,22 @@ __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ 
     }
 }
 
-__global__ void k_masks_reset(FrameState *st, int n, unsigned long long *best)
+// the three chains meet: the region stage's verdict comes first (a frame without a region never looked for its spot
+// in the sequential order: mask_roi_around_center is not reached, util_cylinder.py:1900 raises before)
+__global__ void k_masks_reset(FrameState *st, int n)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
-    st[f].n_joints = 0; st[f].n_joints_all = 0; st[f].n_seg[0] = 0; st[f].n_seg[1] = 0;
-    st[f].gang[0] = st[f].gang[1] = 0; st[f].glen[0] = st[f].glen[1] = 0;
-    best[f] = 0;
+    FrameState &S = st[f];
+    S.n_joints = 0; S.n_joints_all = 0; S.n_seg[0] = 0; S.n_seg[1] = 0;
+    S.gang[0] = S.gang[1] = 0; S.glen[0] = S.glen[1] = 0;
+    if (S.status == CPE_ST_NO_REGION) { S.r0 = 0; S.spot[0] = S.spot[1] = S.spot[2] = S.spot[3] = 0; }
+    else if (S.status == CPE_ST_OK && S.spot_fail) S.status = CPE_ST_NO_SPOT;
+}
+__global__ void k_spot_reset(int n, unsigned long long *best)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) best[f] = 0;
 }
 
 inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
@@ -892,41 +899,49 @@ int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint
     return CPE_OK;
 }
 
-// a-2: hmask, vmask, joints mask (no dependence on the region stage)
-int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, hipStream_t s)
+// a-2: hmask, vmask, joints mask and its components (no dependence on the region stage: own stream)
+int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
 {
-    const size_t total = (size_t)h * w * n;
     CPE_LAUNCH_BEGIN();
-    (void)total;
     const int tiles_x = (w + OT_X - 1) / OT_X, tiles_y = (h + OT_Y - 1) / OT_Y;
     CPE_KLAUNCH(k_open20_joints, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.binary, h, w, tiles_x,
                 tiles_y, B.hmask, B.vmask, B.joints_mask);
     CPE_CHECK_LAUNCH("joints_mask_stage");
-    return CPE_OK;
+    return ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab_p, B.roots_p, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 1);
 }
 
-// a-2/a-4 (joint centroids inside rect), a-5 (spot / roi masks), a-6 (expansion).  Needs st[].rect and mc.
-int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
+// a-5 head: saturated spot -> circle_mask, r0 (depends on the grey frame only: own stream)
+int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
 {
     const size_t total = (size_t)h * w * n;
     int rc;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
-    // joints
-    if ((rc = ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots, st, B.jtmp);
-    CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
-    // spot
+    CPE_KLAUNCH(k_spot_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best_s);
     Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
     {
         const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
         CPE_KLAUNCH((k_blur_fused<9, BLUR_SPOT>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, gray, h, w, tiles_x, tiles_y,
                     t19, (const FrameState *)st, B.g19);
     }
-    if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots, st, B.best);
+    if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab_s, B.roots_s, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 2)) != CPE_OK) return rc;
+    CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots_s, st, B.best_s);
     (void)hipMemsetAsync(B.cm, 255, total, s);
-    CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best, st, B.verts, B.cm);
+    CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm);
+    CPE_CHECK_LAUNCH("spot_stage");
+    return CPE_OK;
+}
+
+// a-2/a-4 (joint centroids inside rect), a-5 (roi masks), a-6 (expansion).  Needs st[].rect and mc, the joints
+// components and the spot.
+int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
+{
+    const size_t total = (size_t)h * w * n;
+    int rc;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    // joints
+    CPE_KLAUNCH(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp);
+    CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // roi masks: (mask & circle_mask & mask_contour) opened 3x3
     {
         const int tiles_x = (w + RT_X - 1) / RT_X, tiles_y = (h + RT_Y - 1) / RT_Y;

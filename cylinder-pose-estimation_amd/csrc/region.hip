@@ -15,7 +15,7 @@
 namespace cpe {
 
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
-            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0);
+            uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0, int cnt_sel = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int invert, int *nrect, FrameState *st, hipStream_t s);
 

@@ -24,11 +24,3 @@ cpe_amd.lib.profile(True)
 det = api.detect_grid_batch(frames, ws); torch.cuda.synchronize()
 rep = cpe_amd.lib.profile_report(); cpe_amd.lib.profile(False)
 print('event profile:', ' | '.join(f"{r[0].split('::')[-1]} x{r[1]} {r[2]:.1f}ms" for r in rep[:int(os.environ.get("CPE_TOP", "10"))]), "| total %.1f ms" % sum(r[2] for r in rep))
-if os.environ.get('CPE_DBG'):
-    stt = ws.state()
-    print('pad0 (max fg trace)', [s_['pad0'] for s_ in stt][:16], 'pad1 (max hole trace)', [s_['pad1'] for s_ in stt][:16], 'pad2 (sum)', [s_['pad2'] for s_ in stt][:16])
-if os.environ.get('CPE_DBG2'):
-    stt = ws.state()
-    import numpy as np
-    for k in ('pad0', 'pad1', 'pad2', 'n_verts', 'n_groups'):
-        print(k, np.mean([s_[k] for s_ in stt]) * (16 if k != 'n_groups' else 1))
