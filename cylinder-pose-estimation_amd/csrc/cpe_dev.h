@@ -76,6 +76,8 @@ struct RegionBuffers {
     unsigned long long *best;
     int *lohi, *hull;
 };
+// optional helper stream of the region stage: the hole borders are followed while the bright sweep runs
+struct RegionSide { hipStream_t s; hipEvent_t clahe_done, dark_done, traced; };
 struct MaskBuffers {
     uint8_t *binary, *hmask, *vmask, *joints_mask, *tmpA, *tmpB, *g19, *cm, *mc, *roi_h, *roi_v, *base_h, *base_v, *exp_h,
         *exp_v, *touch;

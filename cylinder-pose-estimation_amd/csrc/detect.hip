@@ -17,7 +17,8 @@ namespace cpe {
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
             uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0, int cnt_sel = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
-int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s);
+int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s,
+                 const RegionSide *side);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
@@ -117,8 +118,8 @@ __global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
 // two helper streams per process (created on first use; CPE_SERIAL=1 keeps everything on the caller's stream)
 struct SideStreams {
     bool ok = false;
-    hipStream_t s1 = nullptr, s2 = nullptr;
-    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
+    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, e3a = nullptr, e3b = nullptr, e3c = nullptr;
 };
 SideStreams &side_streams()
 {
@@ -134,6 +135,10 @@ SideStreams &side_streams()
     if (!X.s1 && !X.ok) {
         bool good = hipStreamCreateWithFlags(&X.s1, hipStreamNonBlocking) == hipSuccess &&
                     hipStreamCreateWithFlags(&X.s2, hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&X.s3, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.e3a, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.e3b, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.e3c, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.join1, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.join2, hipEventDisableTiming) == hipSuccess;
@@ -229,7 +234,8 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
     if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
     if ((rc = spot_stage(gray, n, h, w, M, st, s2)) != CPE_OK) return rc;
-    if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s)) != CPE_OK) return rc;
+    RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c};
+    if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
     if (X.ok) {
         (void)hipEventRecord(X.join1, X.s1);
         (void)hipEventRecord(X.join2, X.s2);

@@ -1128,7 +1128,8 @@ __global__ void k_region_reset(FrameState *st, int n, unsigned long long *best)
 }  // namespace
 
 
-int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s)
+int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s,
+                 const RegionSide *side)
 {
     const size_t N = (size_t)h * w, total = N * n;
     ClaheGeom g;
@@ -1149,6 +1150,11 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
+    if (side) {   // the 17 one-bit planes only need the CLAHE image
+        (void)hipEventRecord(side->clahe_done, s);
+        (void)hipStreamWaitEvent(side->s, side->clahe_done, 0);
+        if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, side->s)) != CPE_OK) return rc;
+    }
     // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
     // every brighter set and every hole of every binarisation lies inside it
     if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
@@ -1189,9 +1195,15 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
         CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
-    if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
-                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
+    {
+        // hole borders of all thresholds: on the helper stream (if any) beside the bright sweep below
+        hipStream_t ts = side ? side->s : s;
+        if (side) { (void)hipEventRecord(side->dark_done, s); (void)hipStreamWaitEvent(ts, side->dark_done, 0); }
+        else if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ts, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
+                    B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
+        if (side) (void)hipEventRecord(side->traced, ts);
+    }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
     for (int j = 0; j < NTHR; j++) {
@@ -1209,6 +1221,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.bl, B.sw, (int)SW_NL, k, h, w, (const int *)B.cnt2, (int2 *)nullptr, st);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
+    if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
     CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,

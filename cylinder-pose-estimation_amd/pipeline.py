@@ -31,21 +31,26 @@ class FramePipeline:
     """reusable workspaces for chunks of `chunk` stereo frames of size h x w"""
 
     def __init__(self, h, w, K1, K2, T21, radius, chunk=64, device='cuda:0', selector=fit.SEL_CHOOSE_IDX, th=0.3,
-                 fit_mode=fit.FIT_NELDER_MEAD):
+                 fit_mode=fit.FIT_NELDER_MEAD, lanes=1):
         self.h, self.w, self.chunk, self.device = h, w, chunk, torch.device(device)
         self.K1, self.K2, self.T21, self.radius = K1, K2, T21, radius
         self.selector, self.th, self.fit_mode = selector, th, fit_mode
         self.ws = {}
+        # chunks are independent: `lanes` of them are in flight on their own HIP streams (each with its own
+        # workspace), so the serial tails of one chunk (blob grouping, line fitting: one workgroup per frame)
+        # run beside the wide kernels of the next
+        self.lanes = max(1, int(lanes))
+        self._streams = None
 
-    def _ws(self, n_img):
-        if n_img not in self.ws:
-            self.ws[n_img] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
-        return self.ws[n_img]
+    def _ws(self, n_img, lane=0):
+        if (lane, n_img) not in self.ws:
+            self.ws[(lane, n_img)] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
+        return self.ws[(lane, n_img)]
 
-    def run_chunk(self, left, right):
+    def run_chunk(self, left, right, lane=0):
         c = left.shape[0]
         frames = torch.cat([left, right])                 # [2c,h,w]: one detect call for both cameras
-        det = api.detect_grid_batch(frames, self._ws(2 * c))
+        det = api.detect_grid_batch(frames, self._ws(2 * c, lane))
         g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
         g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
         out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th,
@@ -62,7 +67,22 @@ class FramePipeline:
         """left/right: u8 [F,h,w] on the device -> records f64 [F,16]"""
         F = left.shape[0]
         recs = torch.empty((F, REC), dtype=torch.float64, device=left.device)
-        for i0 in range(0, F, self.chunk):
+        n_chunks = (F + self.chunk - 1) // self.chunk
+        if self.lanes == 1 or n_chunks == 1 or left.device.type != 'cuda':
+            for i0 in range(0, F, self.chunk):
+                i1 = min(F, i0 + self.chunk)
+                recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1])[0]
+            return recs
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=left.device) for _ in range(self.lanes)]
+        main = torch.cuda.current_stream(left.device)
+        for st in self._streams:
+            st.wait_stream(main)                          # inputs and `recs` are ready on the caller's stream
+        for k, i0 in enumerate(range(0, F, self.chunk)):
             i1 = min(F, i0 + self.chunk)
-            recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1])[0]
+            lane = k % self.lanes
+            with torch.cuda.stream(self._streams[lane]):
+                recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1], lane)[0]
+        for st in self._streams:
+            main.wait_stream(st)
         return recs
