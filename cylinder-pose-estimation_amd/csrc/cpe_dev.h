@@ -162,11 +162,15 @@ struct BitWin {
     int ws, h;
     unsigned long long *win;     // LDS, row r of this lane at win[r * 64]
     int wx0 = 0, wy0 = INT_MIN / 2;   // padded bit index of window column 0, image row of window row 0
-    __device__ __forceinline__ void load(int x, int y)
+    // (re)fill the window around (x, y).  The window is put ahead of the border's direction of travel: leaving through
+    // the top / bottom row puts the pixel on the bottom / top side of the new window, leaving through the left / right
+    // columns puts it on the right / left side -- borders keep their heading for a while, so a refill lasts about
+    // twice as many steps as a centred window.
+    __device__ __forceinline__ void load(int x, int y, int row_in_win, int col_lo)
     {
-        const int k = (x + 16) >> 5;   // (x + 32 - 16) / 32: the pixel lands in columns 16..47 of the window
+        const int k = (x + 32 - col_lo) >> 5;   // the pixel lands in columns col_lo .. col_lo + 31 of the window
         wx0 = 32 * k;
-        wy0 = y - BW_ROWS / 2;
+        wy0 = y - row_in_win;
 #pragma unroll
         for (int r = 0; r < BW_ROWS; r++) {
             const int yy = wy0 + r;
@@ -179,7 +183,15 @@ struct BitWin {
     {
         int p = x + 32 - wx0, r = y - wy0;
         if (p < 1 || p > 62 || r < 1 || r > BW_ROWS - 2) {
-            load(x, y);
+            const bool fresh = wy0 == INT_MIN / 2;
+            int row = BW_ROWS / 2, col = 16;
+            if (!fresh) {
+                if (r < 1) row = BW_ROWS - 3;          // heading up
+                else if (r > BW_ROWS - 2) row = 2;     // heading down
+                if (p < 1) col = 29;                   // heading left: columns 29..60 (x + 32 >= 32 keeps k >= 0)
+                else if (p > 62) col = 3;              // heading right: columns 3..34
+            }
+            load(x, y, row, col);
             p = x + 32 - wx0; r = y - wy0;
         }
         const unsigned ta = (unsigned)(win[(r - 1) * 64] >> (p - 1)) & 7u;   // bit 0: x - 1, bit 1: x, bit 2: x + 1

@@ -165,13 +165,22 @@ struct StoreVisitor {
     int *counter;
     unsigned short *ids;   // LDS, entry j of this lane at ids[j * 64]: the first CH_DIRECT chunks of the border
     int cur = -1, fill = CH_PTS, nch = 0;
+    int res_next = 0, res_end = 0;   // chunks reserved up front (one atomic per border in the common case)
     bool ok = true;
+    __device__ __forceinline__ void reserve(int expected_points)
+    {
+        const int want = min((expected_points + CH_PTS - 1) / CH_PTS, CH_DIRECT);
+        res_next = atomicAdd(counter, want);
+        res_end = min(res_next + want, MAXCH);
+    }
     __device__ __forceinline__ void point(int x, int y, bool vertex)
     {
         sv.point(x, y, vertex);
         if (!ok) return;
         if (fill == CH_PTS) {
-            const int c = (sv.npts <= MAXCHAIN * CH_PTS) ? atomicAdd(counter, 1) : MAXCH;
+            int c;
+            if (res_next < res_end) c = res_next++;
+            else c = (sv.npts <= MAXCHAIN * CH_PTS) ? atomicAdd(counter, 1) : MAXCH;
             if (c >= MAXCH) { ok = false; return; }
             pool[(size_t)c * 32] = (uint32_t)cur;
             cur = c;
@@ -217,6 +226,8 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     tv.counter = &S[SW_NC + slot];
     tv.ids = s_ids + threadIdx.x;
     tv.ok = is_hole != 0;   // bright components: few are accepted, their borders are followed again instead
+    // a compact hole of n pixels has a border of about 4 sqrt(n) + 4 pixels; reserve for twice that
+    if (is_hole) tv.reserve(8 * (int)sqrtf((float)e.y) + 16);
     StatVisitor &sv = tv.sv;
     bool ok = trace_border(nz, x0, y0, is_hole != 0, tv, max_steps);
     if (!ok) { st[f].overflow = 1; return; }
