@@ -77,12 +77,13 @@ struct RegionBuffers {
     int *lohi, *hull;
 };
 // optional helper stream of the region stage: the hole borders are followed while the bright sweep runs
-struct RegionSide { hipStream_t s; hipEvent_t clahe_done, dark_done, traced; };
+struct RegionSide { hipStream_t s; hipEvent_t clahe_done, dark_done, traced, medians; };
 struct MaskBuffers {
     uint8_t *binary, *hmask, *vmask, *joints_mask, *tmpA, *tmpB, *g19, *cm, *mc, *roi_h, *roi_v, *base_h, *base_v, *exp_h,
         *exp_v, *touch;
     int *lab, *roots, *jtmp, *joints, *verts;
-    int *lab_p, *roots_p, *lab_s, *roots_s;   // label planes / component lists of the joints and spot chains
+    int *lab_p, *roots_p, *lab_s, *roots_s;
+    int *lab_h, *lab_v;                       // union-find planes of the two expanded masks (read by k_lines)   // label planes / component lists of the joints and spot chains
     uint32_t *bits;
     unsigned long long *best, *best_s;
     SegRec *segs;

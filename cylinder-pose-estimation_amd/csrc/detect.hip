@@ -21,7 +21,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                  const RegionSide *side);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
-int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
+int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
+                const RegionSide *side);
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
@@ -119,7 +120,7 @@ __global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
 struct SideStreams {
     bool ok = false;
     hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
-    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, e3a = nullptr, e3b = nullptr, e3c = nullptr;
+    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, e3a = nullptr, e3b = nullptr, e3c = nullptr, e3d = nullptr;
 };
 SideStreams &side_streams()
 {
@@ -139,6 +140,7 @@ SideStreams &side_streams()
                     hipEventCreateWithFlags(&X.e3a, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.e3b, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.e3c, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&X.e3d, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.join1, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&X.join2, hipEventDisableTiming) == hipSuccess;
@@ -234,7 +236,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
     if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
     if ((rc = spot_stage(gray, n, h, w, M, st, s2)) != CPE_OK) return rc;
-    RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c};
+    RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d};
     if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
     if (X.ok) {
         (void)hipEventRecord(X.join1, X.s1);
@@ -242,9 +244,8 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
         (void)hipStreamWaitEvent(s, X.join1, 0);
         (void)hipStreamWaitEvent(s, X.join2, 0);
     }
-    if ((rc = masks_stage(gray, n, h, w, M, st, s)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_h, n, h, w, 0, 0, 1, PL(int, P_LAB0), nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
-    if ((rc = ccl_run(M.exp_v, n, h, w, 0, 0, 1, PL(int, P_LAB1), nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 2)) != CPE_OK) return rc;
+    M.lab_h = PL(int, P_LAB0); M.lab_v = PL(int, P_LAB1);
+    if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
     if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
     if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                           n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),

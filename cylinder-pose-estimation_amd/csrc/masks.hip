@@ -686,13 +686,13 @@ struct SegVisitor {
 
 // one thread per fragment: CHAIN_APPROX_SIMPLE vertices (5..200) -> PCA end points, angle, length
 __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ base_bits, int h, int w, int which,
-                                                  const int *__restrict__ roots, FrameState *__restrict__ st,
+                                                  const int *__restrict__ roots, int cnt_sel, FrameState *__restrict__ st,
                                                   SegRec *__restrict__ segs /* n*MAXSEG */)
 {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (st[f].status != CPE_ST_OK) return;
-    if (k >= min(st[f].n_roots, MAXROOTS)) return;
+    if (k >= min(*root_counter(st[f], cnt_sel), MAXROOTS)) return;
     const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
     __shared__ unsigned long long s_win[BW_ROWS * 64];
@@ -933,7 +933,8 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
 
 // a-2/a-4 (joint centroids inside rect), a-5 (roi masks), a-6 (expansion).  Needs st[].rect and mc, the joints
 // components and the spot.
-int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
+int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
+                const RegionSide *side)
 {
     const size_t total = (size_t)h * w * n;
     int rc;
@@ -942,30 +943,38 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     // joints
     CPE_KLAUNCH(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp);
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
-    // roi masks: (mask & circle_mask & mask_contour) opened 3x3
-    {
-        const int tiles_x = (w + RT_X - 1) / RT_X, tiles_y = (h + RT_Y - 1) / RT_Y;
-        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.hmask,
-                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, (const FrameState *)st, B.roi_h, B.base_h);
-        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.vmask,
-                    (const uint8_t *)B.cm, (const uint8_t *)B.mc, h, w, tiles_x, tiles_y, (const FrameState *)st, B.roi_v, B.base_v);
-    }
-    CPE_CHECK_LAUNCH("masks_stage spot");
-    // expansion
+    // a-5 tail, a-6 and the labelling of the expanded masks, once per line direction.  The two directions share
+    // nothing but their inputs: the vertical one runs on the helper stream (if any) with the spot chain's label plane.
+    const int tiles_x = (w + RT_X - 1) / RT_X, tiles_y = (h + RT_Y - 1) / RT_Y;
+    const size_t bit_words = (size_t)n * h * bit_row_words(w);
+    if (side) { (void)hipEventRecord(side->clahe_done, s); (void)hipStreamWaitEvent(side->s, side->clahe_done, 0); }
     for (int which = 0; which < 2; which++) {
+        hipStream_t q = (which && side) ? side->s : s;
+        const uint8_t *lm = which ? B.vmask : B.hmask;
+        uint8_t *roi = which ? B.roi_v : B.roi_h;
         uint8_t *base = which ? B.base_v : B.base_h;
         uint8_t *exp = which ? B.exp_v : B.exp_h;
-        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 2, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
-        if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, which, B.roots, st,
-                           B.segs + (size_t)which * n * MAXSEG);
-        CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, s, st, which, B.segs + (size_t)which * n * MAXSEG);
-        (void)hipMemsetAsync(B.tmpB, 0, total, s);
-        CPE_KLAUNCH(k_seg_expand, dim3(MAXSEG * 2, n), dim3(256), 0, s, base, h, w, which, st,
-                           B.segs + (size_t)which * n * MAXSEG, B.tmpB);
-        CPE_KLAUNCH(k_or_and, dim3(grid1(total)), dim3(256), 0, s, B.tmpB, base, B.mc, total, exp);
+        uint8_t *tmp = which ? B.tmpA : B.tmpB;
+        int *lab = which ? B.lab_s : B.lab, *roots = which ? B.roots_s : B.roots;
+        const int sel = which ? 2 : 0;
+        uint32_t *bits = B.bits + (which ? bit_words : 0);
+        SegRec *segs = B.segs + (size_t)which * n * MAXSEG;
+        // roi = open3x3(mask & circle_mask & mask_contour), base = close3x3(roi)
+        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, q, lm, (const uint8_t *)B.cm, (const uint8_t *)B.mc,
+                    h, w, tiles_x, tiles_y, (const FrameState *)st, roi, base);
+        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
+        if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, q, st, which, (const SegRec *)segs);
+        (void)hipMemsetAsync(tmp, 0, total, q);
+        CPE_KLAUNCH(k_seg_expand, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp);
+        CPE_KLAUNCH(k_or_and, dim3(grid1(total)), dim3(256), 0, q, (const uint8_t *)tmp, (const uint8_t *)base, (const uint8_t *)B.mc, total, exp);
         CPE_CHECK_LAUNCH("masks_stage expand");
+        // cv2.connectedComponents of the expanded mask: unions only, k_lines resolves the joints' labels
+        if ((rc = ccl_run(exp, n, h, w, 0, 0, 1, which ? B.lab_v : B.lab_h, nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 2)) != CPE_OK)
+            return rc;
     }
+    if (side) { (void)hipEventRecord(side->traced, side->s); (void)hipStreamWaitEvent(s, side->traced, 0); }
     return CPE_OK;
 }
 

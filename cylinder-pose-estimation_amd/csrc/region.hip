@@ -142,9 +142,10 @@ enum {
     SW_BO = SW_BS + NBK,          // + b: first entry of bucket b in the bucket plane
     SW_BC = SW_BO + NBK,          // + b: fill cursor
     SW_NT = SW_BC + NBK,          // + k: holes of threshold k whose border is followed (length of tl[k])
-    SW_NC = SW_NT + NTHR          // + k: border-point chunks in use
+    SW_NC = SW_NT + NTHR,         // + k: border-point chunks in use
+    SW_NA = SW_NC + NTHR          // + k: blobs of threshold k that came from hole borders (they are listed first)
 };
-static_assert(SW_NC + NTHR <= SW_STRIDE, "sweep counters");
+static_assert(SW_NA + NTHR <= SW_STRIDE, "sweep counters");
 
 // one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
 // lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
@@ -292,7 +293,15 @@ __device__ __forceinline__ double median_of(Ptr d, int n, int lane)
 // that bucket's few members are compared with each other -- O(n) instead of the O(n^2) rank count of the general path.
 constexpr int MED_LDS = 1024;
 constexpr int MED_FAST = CH_DIRECT * CH_PTS;
-__global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
+__global__ void k_sw_mark_holes(int *sw, int n)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    for (int t = 0; t < NTHR; t++) sw[(size_t)f * SW_STRIDE + SW_NA + t] = min(sw[(size_t)f * SW_STRIDE + SW_NB + t], MAXB);
+}
+
+// part 0: the blobs of the hole borders [0, NA), part 1: those of the bright components [NA, NB)
+__global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
                                                     const int *__restrict__ blob_d_all, double *__restrict__ dists_all,
                                                     const uint32_t *__restrict__ pool_all,
                                                     const unsigned short *__restrict__ blob_ch_all, FrameState *__restrict__ st)
@@ -303,13 +312,13 @@ __global__ __launch_bounds__(64) void k_blob_median(int *__restrict__ sw, BlobRe
     __shared__ int s_off, s_cnt;
     const int f = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
     int *S = sw + (size_t)f * SW_STRIDE;
-    const int nb = min(S[SW_NB + slot], MAXB);
+    const int nb = part ? min(S[SW_NB + slot], MAXB) : S[SW_NA + slot];
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
     double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXDF;
     const uint32_t *pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
     const unsigned short *blob_ch = blob_ch_all + ((size_t)f * NTHR + slot) * MAXB * CH_DIRECT;
-    for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+    for (int bi = (part ? S[SW_NA + slot] : 0) + blockIdx.x; bi < nb; bi += gridDim.x) {
         const int code = blob_d[bi * 2], n = blob_d[bi * 2 + 1];
         if (code < 0 || n <= 0) continue;
         double r;
@@ -1213,7 +1222,12 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         else if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ts, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
                     B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
+        CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ts, B.sw, n);
         if (side) (void)hipEventRecord(side->traced, ts);
+        // their radii: still beside the bright sweep
+        CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, ts, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
+                    (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st);
+        if (side) (void)hipEventRecord(side->medians, ts);
     }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
@@ -1235,7 +1249,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
-    CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, s, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
+    if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
+    CPE_KLAUNCH(k_blob_median, dim3(32, n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
                 (const unsigned short *)B.blob_ch, st);
     CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(256), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
     CPE_CHECK_LAUNCH("blob merge");
