@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     __shared__ int s_pref[MAXL + 1];
     __shared__ double s_rv[256];
     __shared__ int s_ri[256];
-    __shared__ int s_crow, s_ccol, s_total, s_cq;
+    __shared__ int s_crow, s_ccol, s_total;
     if (t == 0) { o_n[f] = 0; o_center[2 * f] = 0; o_center[2 * f + 1] = 0; }
     if (S.status != CPE_ST_OK) return;
     LinesWS &W = wsall[f];

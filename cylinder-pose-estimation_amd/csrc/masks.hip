@@ -693,7 +693,6 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (st[f].status != CPE_ST_OK) return;
     if (k >= min(*root_counter(st[f], cnt_sel), MAXROOTS)) return;
-    const size_t N = (size_t)h * w;
     const int root = roots[(size_t)f * MAXROOTS + k];
     __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int ws = bit_row_words(w);
@@ -889,7 +888,6 @@ inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
 // cv2.GaussianBlur(img,(7,7),0) for indexing_data (util_cylinder.py:1433)
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s)
 {
-    const size_t total = (size_t)h * w * n;
     Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};
     CPE_LAUNCH_BEGIN();
     const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;

@@ -40,6 +40,8 @@ _SIGS = {
     'cpe_select_triangulate_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 +
                                      [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
     'cpe_multi_frame_terms': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    'cpe_undistort_map': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'cpe_remap_bilinear_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cpe_fit_cylinder_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p] +
                                [C.c_void_p] * 7),
 }

@@ -189,6 +189,18 @@ CPE_API int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, int3
                                        const CpeFitParams *params, double *cyl_raw, double *cyl, double *T,
                                        double *fvals, int32_t *iters, int32_t *status, void *stream);
 
+/* Row f-3: the undistortion pre-step of the CLI entry point, utils/iotool.py:22-39
+ *   undistort_image(image, camera_params) = cv2.undistort(image, IntrinsicMatrix, hstack(Radial, Tangential))
+ * cv2.undistort rebuilds its fixed-point map per image; here the map is built once per camera and applied per frame.
+ *   cpe_undistort_map: K f64[9] row-major and dist f64[n_dist] are HOST pointers (n_dist in {0,4,5,8,12}, OpenCV order
+ *     k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]]); map_xy i16[h,w,2] and map_f u16[h,w] are device buffers in OpenCV's
+ *     CV_16SC2 / CV_16UC1 convention (integer source pixel; 5-bit fractions fy*32 + fx).
+ *   cpe_remap_bilinear_batch: dst[n,h,w] = remap(src[n,h,w], map, INTER_LINEAR, BORDER_CONSTANT 0); src != dst. */
+CPE_API int32_t cpe_undistort_map(const double *K, const double *dist, int32_t n_dist, int32_t h, int32_t w,
+                                  int16_t *map_xy, uint16_t *map_f, void *stream);
+CPE_API int32_t cpe_remap_bilinear_batch(const uint8_t *src, int32_t n, int32_t h, int32_t w, const int16_t *map_xy,
+                                         const uint16_t *map_f, uint8_t *dst, void *stream);
+
 /* Row f-1: the per-frame terms of the multi-frame objective of fitCylinderWPts3sAngs.m:82-94 (`dist`):
  * terms[i] = mean((getDistPts3ToLine(Pts3s{i}, line(T * TAGVcyls{i})) - radius)^2), one wavefront per frame.
  * X f64[n,CPE_MAXP,3], cnt i32[n], TAGVcyl f64[n,16] (row-major getTAGVcyl(pan,tilt)), T f64[16] (device, row-major

@@ -203,3 +203,32 @@ def multi_fit(P, cnt, TAGV, cyl_raw, R):
                         _p(cyl_raw, C.c_double), C.c_double(R), _p(x0, C.c_double), _p(x, C.c_double), _p(T, C.c_double),
                         _p(fv, C.c_double), C.byref(it), C.byref(ev))
     return dict(x0=x0, x=x, T=T, fvals=fv, iters=it.value, evals=ev.value)
+
+
+# ---- row f-3: cv2.undistort restatement (orc_undistort.c) -----------------------------------------------------
+def undistort_map(K, dist, h, w):
+    """-> (map_xy int16 [h,w,2], map_f uint16 [h,w]) as cv2.initUndistortRectifyMap(..., CV_16SC2) inside cv2.undistort"""
+    L = lib()
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
+    d = np.ascontiguousarray(np.asarray(dist, dtype=np.float64).ravel())
+    mxy = np.empty((h, w, 2), dtype=np.int16); mf = np.empty((h, w), dtype=np.uint16)
+    rc = L.orc_undistort_map(K.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_int(d.size), C.c_int(h), C.c_int(w),
+                             mxy.ctypes.data_as(C.c_void_p), mf.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError('orc_undistort_map: singular matrix or unsupported coefficient count')
+    return mxy, mf
+
+
+def remap_bilinear(src, map_xy, map_f):
+    L = lib()
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    L.orc_remap_bilinear(src.ctypes.data_as(C.c_void_p), C.c_int(h), C.c_int(w), np.ascontiguousarray(map_xy).ctypes.data_as(C.c_void_p),
+                         np.ascontiguousarray(map_f).ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+    return dst
+
+
+def undistort(src, K, dist):
+    mxy, mf = undistort_map(K, dist, src.shape[0], src.shape[1])
+    return remap_bilinear(src, mxy, mf)
