@@ -150,7 +150,7 @@ static_assert(SW_NA + NTHR <= SW_STRIDE, "sweep counters");
 // one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
 // lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
 // Border points of the hole traces are kept while the border is followed the first time, in 128-byte chunks of a pool
-// per frame and threshold (word 0: previous chunk of the same border, words 1..31: x | y << 16), so the accepted blobs
+// per frame and threshold (words 0..30: x | y << 16, word 31: previous chunk of the same border), so the accepted blobs
 // need no second pass along their border; k_blob_median turns the points into distances.
 constexpr int CH_PTS = 31;
 constexpr int MAXCH = 8192;            // chunks per frame and threshold
@@ -165,8 +165,9 @@ struct StoreVisitor {
     uint32_t *pool;
     int *counter;
     unsigned short *ids;   // LDS, entry j of this lane at ids[j * 64]: the first CH_DIRECT chunks of the border
-    int cur = -1, fill = CH_PTS, nch = 0;
+    int cur = -1, link = -1, fill = CH_PTS, nch = 0;
     int res_next = 0, res_end = 0;   // chunks reserved up front (one atomic per border in the common case)
+    uint32_t b0 = 0, b1 = 0, b2 = 0;   // points wait in registers until four of them (16 aligned bytes) can go out together
     bool ok = true;
     __device__ __forceinline__ void reserve(int expected_points)
     {
@@ -183,14 +184,31 @@ struct StoreVisitor {
             if (res_next < res_end) c = res_next++;
             else c = (sv.npts <= MAXCHAIN * CH_PTS) ? atomicAdd(counter, 1) : MAXCH;
             if (c >= MAXCH) { ok = false; return; }
-            pool[(size_t)c * 32] = (uint32_t)cur;
+            link = cur;
             cur = c;
             fill = 0;
             if (nch < CH_DIRECT) ids[nch * 64] = (unsigned short)c;
             nch++;
         }
-        pool[(size_t)cur * 32 + 1 + fill] = (uint32_t)x | ((uint32_t)y << 16);
+        const uint32_t p = (uint32_t)x | ((uint32_t)y << 16);
+        const int slot = fill & 3;
         fill++;
+        if (slot == 3) *reinterpret_cast<uint4 *>(pool + (size_t)cur * 32 + fill - 4) = make_uint4(b0, b1, b2, p);
+        else if (fill == CH_PTS) *reinterpret_cast<uint4 *>(pool + (size_t)cur * 32 + 28) = make_uint4(b0, b1, p, (uint32_t)link);
+        else if (slot == 0) b0 = p;
+        else if (slot == 1) b1 = p;
+        else b2 = p;
+    }
+    // points still in registers and the link word of the last chunk
+    __device__ __forceinline__ void flush()
+    {
+        if (!ok || cur < 0 || fill == CH_PTS) return;
+        uint32_t *c = pool + (size_t)cur * 32;
+        const int r = fill & 3, base = fill - r;
+        if (r > 0) c[base] = b0;
+        if (r > 1) c[base + 1] = b1;
+        if (r > 2) c[base + 2] = b2;
+        c[31] = (uint32_t)link;
     }
     __device__ __forceinline__ bool stop() const { return false; }
 };
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     StatVisitor &sv = tv.sv;
     bool ok = trace_border(nz, x0, y0, is_hole != 0, tv, max_steps);
     if (!ok) { st[f].overflow = 1; return; }
+    tv.flush();
     sv.finish();
     double m00, m10, m01;
     moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
                 const int c = __shfl(myid, valid ? i / CH_PTS : 0, 64);
                 v[m] = -1.0;
                 if (valid) {
-                    const uint32_t p = pool[(size_t)c * 32 + 1 + i % CH_PTS];
+                    const uint32_t p = pool[(size_t)c * 32 + i % CH_PTS];
                     const double dx = cx - (double)(int)(p & 0xFFFFu), dy = cy - (double)(int)(p >> 16);
                     v[m] = dx * dx + dy * dy;
                     mn = fmin(mn, v[m]); mx = fmax(mx, v[m]);
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
             __syncthreads();
             if (lane == 0) {
                 int c = code & (PTS_STORED - 1);
-                for (int j = nch - 1; j >= 0; j--) { s_ch[j] = c; c = (int)pool[(size_t)c * 32]; }
+                for (int j = nch - 1; j >= 0; j--) { s_ch[j] = c; c = (int)pool[(size_t)c * 32 + 31]; }
                 s_off = 0;
                 if (n > MED_LDS) s_off = atomicAdd(&S[SW_ND + slot], n);
             }
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
             if (!in_lds && s_off + n > MAXDF) { if (lane == 0) st[f].overflow = 1; continue; }
             double *out = dists + s_off;
             for (int i = lane; i < n; i += 64) {
-                const uint32_t p = pool[(size_t)s_ch[i / CH_PTS] * 32 + 1 + i % CH_PTS];
+                const uint32_t p = pool[(size_t)s_ch[i / CH_PTS] * 32 + i % CH_PTS];
                 const double dx = cx - (double)(int)(p & 0xFFFFu), dy = cy - (double)(int)(p >> 16);
                 const double vv = sqrt(dx * dx + dy * dy);
                 if (in_lds) s_d[i] = vv;
