@@ -11,6 +11,7 @@
 // the hole's raster-first pixel and every outer border at the component's raster-first pixel, so the
 // parallel formulation visits exactly the borders the sequential raster scan does.
 #include "cpe_dev.h"
+#include <stdlib.h>
 
 namespace cpe {
 
@@ -465,7 +466,7 @@ __device__ __forceinline__ int wave_min_int(int v)
 
 __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
                                                     const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
-                                                    Group *__restrict__ groups)
+                                                    Group *__restrict__ groups, int always_replay)
 {
     // location + radius of each group's middle centre (what the tests read)
     __shared__ double sX[MAXG], sY[MAXG], sR[MAXG];
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
                     const int o = __shfl(jm, dd, 64);
                     if (dd != lane && o == jm && jm != INT_MAX) dup = true;
                 }
-                bool serial = __ballot(dup) != 0ull;
+                bool serial = always_replay || __ballot(dup) != 0ull;
                 int gn = 0, pos = 0;
                 bool ins = false, full = false;
                 double nx = 0, ny = 0, nr = 0;
@@ -1271,7 +1272,12 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
     CPE_KLAUNCH(k_blob_median, dim3(32, n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
                 (const unsigned short *)B.blob_ch, st);
-    CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(256), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups);
+    {
+        // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
+        const char *e = getenv("CPE_MERGE_REPLAY");
+        CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(256), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups,
+                    (e && e[0] == '1') ? 1 : 0);
+    }
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);

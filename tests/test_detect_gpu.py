@@ -165,3 +165,51 @@ def test_subpixel_mode_matches_oracle(cpe, orc, gpu, h, w, seed):
         base = S.detect_grid(frames[i].numpy())
         assert not np.array_equal(base['xy'], ref['xy'])                  # the stage does move the points
     assert n_ok >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env', [{'CPE_SERIAL': '1'}, {'CPE_MERGE_REPLAY': '1'}, {'CPE_SERIAL': '1', 'CPE_MERGE_REPLAY': '1'}])
+def test_execution_variants_give_identical_results(cpe, orc, gpu, env, monkeypatch):
+    """stream overlap on / off and the two paths of the batched blob grouping (lane-per-blob vs in-order replay) are
+    scheduling choices only: tables, statuses and the order-dependent intermediates must not change by a bit"""
+    frames = _frames(600, 800, 3, 21).to(gpu)
+    keys = ('xy', 'id', 'n', 'center', 'status')
+    base = cpe.api.detect_grid_batch(frames)
+    torch.cuda.synchronize()
+    ref = {k: base[k].clone() for k in keys}
+    ref_planes = {k: base['ws'].plane(k).clone() for k in ('mask_contour', 'exp_h', 'exp_v')}
+    ref_state = base['ws'].state()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = cpe.api.detect_grid_batch(frames)
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(alt[k], ref[k]), k
+    for k, v in ref_planes.items():
+        assert torch.equal(alt['ws'].plane(k), v), k
+    st = alt['ws'].state()
+    for a, b in zip(st, ref_state):
+        for fld in ('n_groups', 'n_kp', 'rect0', 'rect1', 'rect2', 'rect3', 'r0', 'n_joints', 'n_rows', 'n_cols'):
+            assert a[fld] == b[fld], fld
+
+
+@pytest.mark.gpu
+def test_full_size_batch_invariance(cpe, orc, gpu):
+    """BASELINE-size frames (1920x1200), too many for the oracle in a test: size-independent properties instead.
+    Frames are independent, so the pose records may not depend on how the batch is chunked, on the number of chunks in
+    flight, or on the order of the frames; and a frame's record equals the one it gets when processed alone."""
+    from cpe_amd import synth, pipeline
+    F = 24
+    b = synth.render_batch(F, 1200, 1920, seed=31, device=gpu, with_gt=False)
+    mk = lambda chunk, lanes: pipeline.FramePipeline(1200, 1920, b['K1'], b['K2'], b['T21'], b['radius'], chunk=chunk,
+                                                     device=gpu, lanes=lanes)
+    ref = mk(24, 1).run(b['left'], b['right'])
+    torch.cuda.synchronize()
+    assert torch.equal(mk(5, 1).run(b['left'], b['right']), ref)            # ragged chunks
+    assert torch.equal(mk(8, 3).run(b['left'], b['right']), ref)            # three chunks in flight
+    perm = torch.randperm(F, generator=torch.Generator().manual_seed(1)).to(gpu)
+    assert torch.equal(mk(24, 1).run(b['left'][perm].contiguous(), b['right'][perm].contiguous()), ref[perm])
+    one = mk(1, 1).run(b['left'][7:8], b['right'][7:8])
+    assert torch.equal(one[0], ref[7])
+    n_pts, iters, fit_st, dl, dr = pipeline.unpack_counters(ref[:, 15])
+    assert int(((fit_st == 0) & (dl == 0) & (dr == 0)).sum()) >= F - 2       # the synthetic frames are detectable
