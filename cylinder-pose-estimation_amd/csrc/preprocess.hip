@@ -205,22 +205,33 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
     {
         GView G{s.buf2, gx0 - RG, gy0 - RG, w, h};
         double *bb = s.buf1;
+        // tiles whose E range keeps 2 pixels away from every frame border (uniform per workgroup): central differences
+        // only, no clamping -- the same operations in the same order as the general path takes for such pixels
+        const bool inner = gx0 - RE - 2 >= 0 && gx0 + TX + RE + 2 <= w - 1 && gy0 - RE - 2 >= 0 && gy0 + TY + RE + 2 <= h - 1;
         for (int i = tid; i < EH * EW; i += NT) {
             int ry = i / EW, rx = i - ry * EW;
             int y = cpe::clampi(gy0 - RE + ry, 0, h - 1), x = cpe::clampi(gx0 - RE + rx, 0, w - 1);
             double m00, m01, m11;
-            if (x == 0) m00 = G.gx(y, 1) - G.gx(y, 0);
-            else if (x == w - 1) m00 = G.gx(y, w - 1) - G.gx(y, w - 2);
-            else m00 = (G.gx(y, x + 1) - G.gx(y, x - 1)) / 2.0;
-            if (y == 0) {
-                m01 = G.gx(1, x) - G.gx(0, x);
-                m11 = G.gy(1, x) - G.gy(0, x);
-            } else if (y == h - 1) {
-                m01 = G.gx(h - 1, x) - G.gx(h - 2, x);
-                m11 = G.gy(h - 1, x) - G.gy(h - 2, x);
+            if (inner) {
+                const double *g = &s.buf2[(ry + RG - RE) * GW_ + rx + RG - RE];   // G at (y, x)
+                const double c = g[0];
+                m00 = ((g[2] - c) / 2.0 - (c - g[-2]) / 2.0) / 2.0;
+                m01 = ((g[GW_ + 1] - g[GW_ - 1]) / 2.0 - (g[-GW_ + 1] - g[-GW_ - 1]) / 2.0) / 2.0;
+                m11 = ((g[2 * GW_] - c) / 2.0 - (c - g[-2 * GW_]) / 2.0) / 2.0;
             } else {
-                m01 = (G.gx(y + 1, x) - G.gx(y - 1, x)) / 2.0;
-                m11 = (G.gy(y + 1, x) - G.gy(y - 1, x)) / 2.0;
+                if (x == 0) m00 = G.gx(y, 1) - G.gx(y, 0);
+                else if (x == w - 1) m00 = G.gx(y, w - 1) - G.gx(y, w - 2);
+                else m00 = (G.gx(y, x + 1) - G.gx(y, x - 1)) / 2.0;
+                if (y == 0) {
+                    m01 = G.gx(1, x) - G.gx(0, x);
+                    m11 = G.gy(1, x) - G.gy(0, x);
+                } else if (y == h - 1) {
+                    m01 = G.gx(h - 1, x) - G.gx(h - 2, x);
+                    m11 = G.gy(h - 1, x) - G.gy(h - 2, x);
+                } else {
+                    m01 = (G.gx(y + 1, x) - G.gx(y - 1, x)) / 2.0;
+                    m11 = (G.gy(y + 1, x) - G.gy(y - 1, x)) / 2.0;
+                }
             }
             double t1 = m01 * m01;
             double t2 = 4.0 * t1;
