@@ -464,16 +464,19 @@ __device__ __forceinline__ int wave_min_int(int v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
+constexpr int MG_NT = 1024;   // threads of k_blob_merge (16 wavefronts: the group search and the pair tests are split over them)
+__global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
                                                     const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
                                                     Group *__restrict__ groups, int always_replay)
 {
     // location + radius of each group's middle centre (what the tests read)
     __shared__ double sX[MAXG], sY[MAXG], sR[MAXG];
     __shared__ double bX[64], bY[64], bR[64];
-    __shared__ double pl[64][GCAP * 3];   // centre lists of the groups the batch touches
+    __shared__ double pl[GCAP * 3][64];   // centre lists of the groups the batch touches: [element][slot], lanes = slots
+    __shared__ double cX[64], cY[64], cR[64];   // middle centre each blob's group gets if the blob is inserted
+    __shared__ int cG[64], s_bad[64];
     __shared__ int pn[64], pg[64], pd[64], s_jm[64], s_mod[64];
-    __shared__ int s_ng, s_serial;
+    __shared__ int s_ng, s_serial, s_adv;
     const int f = blockIdx.x, t = threadIdx.x, lane = t & 63;
     FrameState &S = st[f];
     int *ord = order + (size_t)f * MAXB;
@@ -482,24 +485,24 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
     for (int thr = 0; thr < NTHR; thr++) {
         const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + thr], MAXB);
         const BlobRec *B = blobs_all + ((size_t)f * NTHR + thr) * MAXB;
-        for (int i = t; i < nb; i += 256) {
+        for (int i = t; i < nb; i += MG_NT) {
             int ki = B[i].key, rank = 0;
             for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0;
             ord[rank] = i;
         }
         __syncthreads();
         const int ng0 = ng;   // centres of this threshold are only compared with groups of the earlier ones
-        for (int q0 = 0; q0 < nb; q0 += 64) {
+        for (int q0 = 0; q0 < nb;) {
             const int qn = min(64, nb - q0);
             if (t < 64) {
                 if (t < qn) { const BlobRec &c = B[ord[q0 + t]]; bX[t] = c.x; bY[t] = c.y; bR[t] = c.r; }
                 s_jm[t] = INT_MAX; pg[t] = -1; pd[t] = 0;
             }
             __syncthreads();
-            // 1. first match against the state at the start of the batch: lane = blob, each wavefront walks a quarter
+            // 1. first match against the state at the start of the batch: lane = blob, each wavefront walks a sixteenth
             //    of the groups (their centres are LDS broadcasts)
             {
-                const int per = (ng0 + 3) / 4, jlo = (t >> 6) * per, jhi = min(jlo + per, ng0);
+                const int per = (ng0 + MG_NT / 64 - 1) / (MG_NT / 64), jlo = (t >> 6) * per, jhi = min(jlo + per, ng0);
                 const bool act = lane < qn;
                 const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
                 int first = act ? INT_MAX : -1;
@@ -521,64 +524,69 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
                 if (first) pg[t] = g;
             }
             __syncthreads();
-            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += 256) {
+            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += MG_NT) {
                 const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
                 const int g = pg[q];
                 if (g >= 0) {
                     if (e == GCAP * 3) pn[q] = G[g].n;
-                    else pl[q][e] = G[g].c[e / 3][e % 3];
+                    else pl[e][q] = G[g].c[e / 3][e % 3];
                 }
             }
             __syncthreads();
-            // 3. Blobs of one batch rarely interact: if no two of them found the same group, and no group's new middle
-            //    centre draws in a later blob of the batch (tested pairwise, lane = blob), every lane inserts its own
-            //    blob at once.  Otherwise the batch is replayed in order by the code below (one wavefront; LDS
-            //    operations of a wavefront execute in order).
+            // 3. Blobs of one batch rarely interact.  A blob is "clean" if no earlier blob of the batch found the same
+            //    group and no earlier blob's group, with the middle centre it gets, would take this blob first (tested
+            //    pairwise, lane = blob).  All blobs before the first unclean one insert themselves at once (lane per
+            //    blob) and the next batch starts AT that blob -- as lane 0 it sees the updated state and is clean by
+            //    definition.  If the clean prefix is short the batch is replayed in order instead (code below).
+            const bool act = lane < qn;
+            const int jm = act ? s_jm[lane] : INT_MAX;
+            const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
+            int gn = 0, pos = 0;
+            bool ins = false, full = false;
+            double nx = 0, ny = 0, nr = 0;
             if (t < 64) {
-                const bool act = lane < qn;
-                const int jm = act ? s_jm[lane] : INT_MAX;
-                const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
-                bool dup = false;
-                for (int dd = 0; dd < 64; dd++) {
-                    const int o = __shfl(jm, dd, 64);
-                    if (dd != lane && o == jm && jm != INT_MAX) dup = true;
-                }
-                bool serial = always_replay || __ballot(dup) != 0ull;
-                int gn = 0, pos = 0;
-                bool ins = false, full = false;
-                double nx = 0, ny = 0, nr = 0;
-                if (!serial) {
-                    if (jm != INT_MAX) {
-                        gn = pn[lane];   // unique group: its slot is this blob's own
-                        full = gn >= GCAP;
-                        ins = !full;
-                        if (ins) {
-                            for (int k = 0; k < gn; k++) pos += !(cr < pl[lane][3 * k + 2]) ? 1 : 0;
-                            const int m = (gn + 1) / 2, src = m < pos ? m : m - 1;
-                            if (m == pos) { nx = cx; ny = cy; nr = cr; }
-                            else { nx = pl[lane][3 * src]; ny = pl[lane][3 * src + 1]; nr = pl[lane][3 * src + 2]; }
-                        }
-                    }
-                    // would an earlier blob's group, with its new middle centre, take this blob first?
-                    bool hit = false;
-                    for (int dd = 0; dd < 64; dd++) {
-                        const int og = __shfl(ins ? jm : -1, dd, 64);
-                        const double ox = __shfl(nx, dd, 64), oy = __shfl(ny, dd, 64), orr = __shfl(nr, dd, 64);
-                        if (dd < lane && act && og >= 0 && og < jm && blob_joins(ox, oy, orr, cx, cy, cr)) hit = true;
-                    }
-                    serial = __ballot(hit) != 0ull;
-                }
-                if (!serial) {
+                const bool own = jm != INT_MAX && pg[lane] == jm;   // first blob of the batch with this group: slot = lane
+                if (own) {
+                    gn = pn[lane];
+                    full = gn >= GCAP;
+                    ins = !full;
                     if (ins) {
+                        for (int k = 0; k < gn; k++) pos += !(cr < pl[3 * k + 2][lane]) ? 1 : 0;
+                        const int m = (gn + 1) / 2, src = m < pos ? m : m - 1;
+                        if (m == pos) { nx = cx; ny = cy; nr = cr; }
+                        else { nx = pl[3 * src][lane]; ny = pl[3 * src + 1][lane]; nr = pl[3 * src + 2][lane]; }
+                    }
+                }
+                cG[lane] = ins ? jm : -1; cX[lane] = nx; cY[lane] = ny; cR[lane] = nr;
+                s_bad[lane] = (act && jm != INT_MAX && !own) ? 1 : 0;
+            }
+            __syncthreads();
+            {   // pair tests: wavefront v checks the blobs dd = 4v .. 4v+3 against every later blob (lane)
+                bool hit = false;
+                const int d0 = (t >> 6) * (64 / (MG_NT / 64));
+                for (int dd = d0; dd < d0 + 64 / (MG_NT / 64); dd++) {
+                    const int og = cG[dd];
+                    if (dd < lane && act && og >= 0 && og < jm && blob_joins(cX[dd], cY[dd], cR[dd], cx, cy, cr)) hit = true;
+                }
+                if (hit) s_bad[lane] = 1;
+            }
+            __syncthreads();
+            if (t < 64) {
+                const unsigned long long bb = __ballot(s_bad[lane] != 0);
+                const int clean = bb ? __ffsll((long long)bb) - 1 : qn;   // >= 1: lane 0 has no earlier blob
+                const bool serial = always_replay || (clean < qn && clean < 8);
+                if (!serial) {
+                    const bool mine = lane < clean;
+                    if (mine && ins) {
                         for (int k = gn - 1; k >= pos; k--) {
-                            pl[lane][3 * k + 3] = pl[lane][3 * k]; pl[lane][3 * k + 4] = pl[lane][3 * k + 1]; pl[lane][3 * k + 5] = pl[lane][3 * k + 2];
+                            pl[3 * k + 3][lane] = pl[3 * k][lane]; pl[3 * k + 4][lane] = pl[3 * k + 1][lane]; pl[3 * k + 5][lane] = pl[3 * k + 2][lane];
                         }
-                        pl[lane][3 * pos] = cx; pl[lane][3 * pos + 1] = cy; pl[lane][3 * pos + 2] = cr;
+                        pl[3 * pos][lane] = cx; pl[3 * pos + 1][lane] = cy; pl[3 * pos + 2][lane] = cr;
                         pn[lane] = gn + 1; pd[lane] = 1;
                         sX[jm] = nx; sY[jm] = ny; sR[jm] = nr;
                     }
-                    if (full) S.overflow = 1;
-                    const bool fresh = act && jm == INT_MAX;
+                    if (mine && full) S.overflow = 1;
+                    const bool fresh = mine && jm == INT_MAX;
                     const unsigned long long fb = __ballot(fresh);
                     const int gi = ng + __popcll(fb & ((1ull << lane) - 1ull));
                     if (fresh) {
@@ -590,8 +598,8 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
                         } else S.overflow = 1;
                     }
                     ng = min(ng + __popcll(fb), MAXG);
-                    if (t == 0) s_ng = ng;
-                }
+                    if (t == 0) { s_ng = ng; s_adv = clean; }
+                } else if (t == 0) s_adv = qn;
                 if (t == 0) s_serial = serial ? 1 : 0;
             }
             __syncthreads();
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
                             // insertion behind the last centre whose radius is not larger (the list is sorted by radius)
                             double ex = 0, ey = 0, er = 0;
                             if (lane < GCAP) {
-                                if (slot >= 0) { ex = pl[slot][3 * lane]; ey = pl[slot][3 * lane + 1]; er = pl[slot][3 * lane + 2]; }
+                                if (slot >= 0) { ex = pl[3 * lane][slot]; ey = pl[3 * lane + 1][slot]; er = pl[3 * lane + 2][slot]; }
                                 else { ex = g.c[lane][0]; ey = g.c[lane][1]; er = g.c[lane][2]; }
                             }
                             const int pos = __popcll(__ballot(lane < gn && !(cr < er)));
@@ -631,9 +639,9 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
                             if (m == pos) { sx = cx; sy = cy; sr = cr; }
                             __builtin_amdgcn_wave_barrier();   // all lanes hold their element: now overwrite (LDS ops of a wave are in order)
                             if (slot >= 0) {
-                                if (lane >= pos && lane < gn) { pl[slot][3 * lane + 3] = ex; pl[slot][3 * lane + 4] = ey; pl[slot][3 * lane + 5] = er; }
+                                if (lane >= pos && lane < gn) { pl[3 * lane + 3][slot] = ex; pl[3 * lane + 4][slot] = ey; pl[3 * lane + 5][slot] = er; }
                                 if (lane == 0) {
-                                    pl[slot][3 * pos] = cx; pl[slot][3 * pos + 1] = cy; pl[slot][3 * pos + 2] = cr;
+                                    pl[3 * pos][slot] = cx; pl[3 * pos + 1][slot] = cy; pl[3 * pos + 2][slot] = cr;
                                     pn[slot] = gn + 1; pd[slot] = 1;
                                 }
                             } else {
@@ -662,14 +670,15 @@ __global__ __launch_bounds__(256) void k_blob_merge(FrameState *__restrict__ st,
             __syncthreads();
             ng = s_ng;
             // 4. changed lists back to HBM
-            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += 256) {
+            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += MG_NT) {
                 const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
                 const int g = pg[q];
                 if (g >= 0 && pd[q]) {
                     if (e == GCAP * 3) G[g].n = pn[q];
-                    else if (e < pn[q] * 3) G[g].c[e / 3][e % 3] = pl[q][e];
+                    else if (e < pn[q] * 3) G[g].c[e / 3][e % 3] = pl[e][q];
                 }
             }
+            q0 += s_adv;
             __syncthreads();
         }
         __syncthreads();
@@ -1275,7 +1284,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     {
         // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
         const char *e = getenv("CPE_MERGE_REPLAY");
-        CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(256), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups,
+        CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(MG_NT), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups,
                     (e && e[0] == '1') ? 1 : 0);
     }
     CPE_CHECK_LAUNCH("blob merge");
