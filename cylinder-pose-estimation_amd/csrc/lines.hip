@@ -246,32 +246,46 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     if (t == 0) s_ovf = 0;
     __syncthreads();
 
-    // group_points_by_label: groups in order of first appearance (threads 0 and 64: one side each)
-    if (t == 0 || t == 64) {
-        const int sd = t >> 6;
-        int ng = 0;
-        for (int i = 0; i < nj; i++) {
-            int jx = J[2 * i], jy = J[2 * i + 1];
-            if (jx < 0 || jx >= w || jy < 0 || jy >= h) continue;
-            if (!E[sd][(size_t)jy * w + jx]) continue;   // background label
-            int lab = uf_find(L[sd], jy * w + jx);
-            int g = -1;
-            for (int k = 0; k < ng; k++)
-                if (W.glabel[sd][k] == lab) { g = k; break; }
-            if (g < 0) {
-                if (ng == MAXL) { s_ovf = 1; continue; }
-                g = ng++;
-                W.glabel[sd][g] = lab;
-                W.gn[sd][g] = 0;
-            }
-            int q = W.gn[sd][g];
-            if (q < MAXLP) {
-                W.gpts[sd][g][q][0] = (double)jx;
-                W.gpts[sd][g][q][1] = (double)jy;
-                W.gn[sd][g] = q + 1;
-            } else s_ovf = 1;
+    // group_points_by_label, groups in order of first appearance.
+    // a) every thread resolves labels (union-find roots) of its share of the joints for both masks;
+    // b) wavefront 0 / 1 walk the joints of side 0 / 1 in order with one lane per group: a ballot finds the joint's group.
+    __shared__ int s_lab[2][MAXJ];
+    for (int i = t; i < nj; i += 256) {
+        const int jx = J[2 * i], jy = J[2 * i + 1];
+        const bool inb = !(jx < 0 || jx >= w || jy < 0 || jy >= h);
+        for (int sd = 0; sd < 2; sd++) {
+            int lab = -1;
+            if (inb && E[sd][(size_t)jy * w + jx]) lab = uf_find(L[sd], jy * w + jx);   // else: background label / skipped
+            s_lab[sd][i] = lab;
         }
-        s_ng[sd] = ng;
+    }
+    __syncthreads();
+    if (t < 128) {
+        const int sd = t >> 6, lane = t & 63;
+        int ng = 0, my_lab = -2, my_n = 0;   // lane k owns group k (MAXL == 64)
+        bool ovf = false;
+        for (int i = 0; i < nj; i++) {
+            const int lab = s_lab[sd][i];
+            if (lab < 0) continue;
+            const unsigned long long mb = __ballot(lane < ng && my_lab == lab);
+            int g;
+            if (mb) g = __ffsll((long long)mb) - 1;
+            else {
+                if (ng == MAXL) { ovf = true; continue; }
+                g = ng++;
+                if (lane == g) { my_lab = lab; my_n = 0; }
+            }
+            if (lane == g) {
+                if (my_n < MAXLP) {
+                    W.gpts[sd][g][my_n][0] = (double)J[2 * i];
+                    W.gpts[sd][g][my_n][1] = (double)J[2 * i + 1];
+                    my_n++;
+                } else ovf = true;
+            }
+        }
+        if (lane < ng) { W.glabel[sd][lane] = my_lab; W.gn[sd][lane] = my_n; }
+        if (__ballot(ovf)) s_ovf = 1;
+        if (lane == 0) s_ng[sd] = ng;
     }
     __syncthreads();
     // sort_rows: stable by min y (rows AND cols), then create_dummy_rows_cols + fit (degree 2)
