@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             if (is_root) {
                 int k = base + __popcll(rb & ((1ull << lane) - 1ull));
                 if (k < MAXROOTS) roots[f * MAXROOTS + k] = i;
-                else st[f].overflow = 1;
+                else set_overflow(st[f], OVF_ROOTS);
             }
         }
     }

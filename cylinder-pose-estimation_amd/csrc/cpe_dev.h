@@ -5,7 +5,8 @@
 namespace cpe {
 
 // ---------------------------------------------------------------- per-image state kept in the workspace
-constexpr int MAXROOTS = 32768;  // connected components considered per image and pass
+constexpr int MAXROOTS = 65536;   // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
+constexpr int MAXSWL = 32768;     // components per threshold of the blob sweep (dark away from the border / bright)
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
 constexpr int MAXB = 4096;       // blobs per threshold
 constexpr int MAXG = 2048;       // blob groups (key-point candidates)
@@ -65,6 +66,7 @@ struct RegionBuffers {
     int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
     uint32_t *pool;   // border points of the hole traces (chunked)
     unsigned short *blob_ch;   // first 16 chunk ids of every blob's border
+    int maxch, maxdf;          // capacities per frame and threshold: border-point chunks, distance scratch (doubles)
     uint32_t *bits;   // 17 one-bit planes per frame (threshold images), reused for single mask planes later
     int2 *hl, *bl, *tl;   // per-threshold component lists of the blob sweep (dark / bright)
     unsigned int *hist;
@@ -88,6 +90,11 @@ struct MaskBuffers {
     unsigned long long *best, *best_s;
     SegRec *segs;
 };
+
+// FrameState::overflow is a bit mask of the fixed capacity that was exceeded (any bit => CPE_ST_OVERFLOW)
+enum { OVF_ROOTS = 1, OVF_LINES = 2, OVF_TRACE = 4, OVF_JOINTS = 8, OVF_VERTS = 16, OVF_SEGS = 32, OVF_KERNEL = 64,
+       OVF_EXPAND = 128, OVF_BLOBS = 256, OVF_DISTS = 512, OVF_GROUPS = 1024, OVF_SWEEP = 2048 };
+__device__ __forceinline__ void set_overflow(FrameState &S, int bit) { atomicOr(&S.overflow, bit); }
 
 // which per-frame component counter a labelling pass fills: 0 the main chain, 1 joints chain, 2 spot chain
 __device__ __forceinline__ int *root_counter(FrameState &S, int sel)

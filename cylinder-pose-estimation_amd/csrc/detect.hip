@@ -45,6 +45,10 @@ enum Plane {
 
 static_assert(P_COUNT <= 64, "Layout arrays too small");
 
+// capacities of the blob sweep that grow with the frame (border points per threshold ~ cells x perimeter)
+static int region_maxch(int h, int w) { long long v = (long long)h * w / 256; return (int)std::min(65535LL, std::max(8192LL, v)); }
+static int region_maxdf(int h, int w) { long long v = (long long)h * w / 32; return (int)std::max(65536LL, v); }
+
 Layout make_layout(int n, int h, int w)
 {
     Layout L;
@@ -66,8 +70,8 @@ Layout make_layout(int n, int h, int w)
     per[P_BLOBS] = (size_t)17 * MAXB * sizeof(BlobRec);
     per[P_BLOB_D] = (size_t)17 * MAXB * 2 * sizeof(int);
     per[P_ORDER] = (size_t)MAXB * sizeof(int);
-    per[P_DISTS] = (size_t)17 * 65536 * sizeof(double);
-    per[P_POOL] = (size_t)17 * 8192 * 128;
+    per[P_DISTS] = (size_t)17 * region_maxdf(h, w) * sizeof(double);
+    per[P_POOL] = (size_t)17 * region_maxch(h, w) * 128;
     per[P_BLOB_CH] = (size_t)17 * MAXB * 16 * sizeof(unsigned short);
     per[P_GROUPS] = (size_t)MAXG * sizeof(Group);
     per[P_LOHI] = (size_t)2 * w * sizeof(int);
@@ -77,7 +81,7 @@ Layout make_layout(int n, int h, int w)
     per[P_LAB2] = N * 4;
     per[P_LAB3] = N * 4;
     per[P_SW] = 192 * sizeof(int);
-    per[P_TL] = (size_t)17 * MAXROOTS * sizeof(int2);
+    per[P_TL] = (size_t)17 * MAXSWL * sizeof(int2);
     per[P_BK] = N * 4;
     per[P_LABP] = N * 4;
     per[P_LABS] = N * 4;
@@ -85,8 +89,8 @@ Layout make_layout(int n, int h, int w)
     per[P_ROOTSS] = (size_t)MAXROOTS * sizeof(int);
     per[P_BEST2] = sizeof(unsigned long long);
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);
-    per[P_HL] = (size_t)17 * MAXROOTS * sizeof(int2);
-    per[P_BL] = (size_t)17 * MAXROOTS * sizeof(int2);
+    per[P_HL] = (size_t)17 * MAXSWL * sizeof(int2);
+    per[P_BL] = (size_t)17 * MAXSWL * sizeof(int2);
     per[P_SUBPIX] = (size_t)2 * MAXL * 2 * (size_t)(std::max(h, w) + 128) * sizeof(float);
     size_t o = 0;
     for (int i = 0; i < P_COUNT; i++) {
@@ -206,7 +210,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     RegionBuffers R;
     R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
     R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.lab2 = PL(int, P_LAB2); R.cnt2 = PL(int, P_LAB3);
-    R.sw = PL(int, P_SW); R.hl = PL(int2, P_HL); R.bl = PL(int2, P_BL); R.tl = PL(int2, P_TL); R.bk = PL(int, P_BK); R.bits = PL(uint32_t, P_BITS); R.pool = PL(uint32_t, P_POOL); R.blob_ch = PL(unsigned short, P_BLOB_CH); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
+    R.sw = PL(int, P_SW); R.hl = PL(int2, P_HL); R.bl = PL(int2, P_BL); R.tl = PL(int2, P_TL); R.bk = PL(int, P_BK); R.bits = PL(uint32_t, P_BITS); R.pool = PL(uint32_t, P_POOL); R.blob_ch = PL(unsigned short, P_BLOB_CH); R.maxch = region_maxch(h, w); R.maxdf = region_maxdf(h, w); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
     R.blobs = PL(BlobRec, P_BLOBS); R.blob_d = PL(int, P_BLOB_D); R.order = PL(int, P_ORDER); R.dists = PL(double, P_DISTS);
     R.groups = PL(Group, P_GROUPS); R.best = PL(unsigned long long, P_BEST); R.lohi = PL(int, P_LOHI); R.hull = PL(int, P_HULL);
     MaskBuffers M;

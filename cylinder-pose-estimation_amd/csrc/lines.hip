@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     if (t == 0) {
         o_n[f] = nout;
         o_center[2 * f] = cx; o_center[2 * f + 1] = cy;
-        if (total > CPE_MAXP || s_ovf) S.overflow = 1;
+        if (total > CPE_MAXP || s_ovf) set_overflow(S, OVF_LINES);
     }
 }
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restric
     const int root = roots[(size_t)f * MAXROOTS + k];
     MaskPred nz{jm + f * N, w, h};
     StatVisitor sv;
-    if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { st[f].overflow = 1; return; }
+    if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { set_overflow(st[f], OVF_TRACE); return; }
     sv.finish();
     double m00, m10, m01;
     moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restric
     const int *r = st[f].rect;
     if (!(r[0] <= cx && cx < r[0] + r[2] && r[1] <= cy && cy < r[1] + r[3])) return;
     int q = atomicAdd(&st[f].n_joints, 1);
-    if (q >= MAXJ) { st[f].overflow = 1; return; }
+    if (q >= MAXJ) { set_overflow(st[f], OVF_JOINTS); return; }
     int *o = jtmp + ((size_t)f * MAXJ + q) * 3;
     o[0] = cx; o[1] = cy; o[2] = root;
 }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void k_spot_area(const uint8_t *__restrict__ g1
     const int root = roots[(size_t)f * MAXROOTS + k];
     ThreshPred nz{g19 + f * N, w, h, 240};
     StatVisitor sv;
-    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
     sv.finish();
     long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;
     // max(contours, key=contourArea): first maximum in list order = latest discovered among equals; area 0 counts
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64) void k_spot_ellipse(const uint8_t *__restrict__
     ThreshPred nz{g19 + f * N, w, h, 240};
     VertVisitor vv{verts + (size_t)f * MAXV * 2, MAXV};
     trace_border(nz, root % w, root / w, false, vv, 8 * (w + h) + (1 << 20));
-    if (vv.n > MAXV) { S.overflow = 1; vv.n = MAXV; }
+    if (vv.n > MAXV) { set_overflow(S, OVF_VERTS); vv.n = MAXV; }
     float cx, cy, rad;
     min_enclosing_circle(vv.v, vv.n, cx, cy, rad);
     int icx = (int)cx, icy = (int)cy;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
     float pts[400];
     SegVisitor sv{pts};
-    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
     const int n = sv.n;
     if (n < 5 || n > 200) return;
     // get_pca_endpoints
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     float at = (float)atan2((double)dy, (double)dx);
     float deg = at * (float)(180.0 / 3.14159265358979323846);
     int q = atomicAdd(&st[f].n_seg[which], 1);
-    if (q >= MAXSEG) { st[f].overflow = 1; return; }
+    if (q >= MAXSEG) { set_overflow(st[f], OVF_SEGS); return; }
     SegRec &r = segs[(size_t)f * MAXSEG + q];
     r.p1x = p1x; r.p1y = p1y; r.p2x = p2x; r.p2y = p2y; r.angle = -deg; r.len = length; r.valid = 1;
 }
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ 
     const float glen = S.glen[which], gang = S.gang[which];
     if ((double)r.len > 0.8 * (double)glen) return;
     const int ks = 91 + S.r0;
-    if (ks > EXP_MAXKS) { if (t == 0) S.overflow = 1; return; }
+    if (ks > EXP_MAXKS) { if (t == 0) set_overflow(S, OVF_KERNEL); return; }
     const float ak = fabsf(r.angle - gang) > 5.0f ? gang : r.angle;
     const int a = ks / 2, half = 7;
     const size_t N = (size_t)h * w;
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ 
     for (int i = t; i < bw * bh; i += 256) dil[i] = 0;
     __syncthreads();
     const int nk = min(s_nk, 4096), np = s_np;
-    if (s_nk > 4096 && t == 0) S.overflow = 1;
+    if (s_nk > 4096 && t == 0) set_overflow(S, OVF_EXPAND);
     for (int i = t; i < nk * np; i += 256) {
         int p = i / nk, k = i - p * nk;
         int xx = ppix[p][0] - koff[k][0], yy = ppix[p][1] - koff[k][1];

@@ -154,17 +154,17 @@ static_assert(SW_NA + NTHR <= SW_STRIDE, "sweep counters");
 // per frame and threshold (words 0..30: x | y << 16, word 31: previous chunk of the same border), so the accepted blobs
 // need no second pass along their border; k_blob_median turns the points into distances.
 constexpr int CH_PTS = 31;
-constexpr int MAXCH = 8192;            // chunks per frame and threshold
+// chunks per frame and threshold: RegionBuffers::maxch = clamp(h*w/256, 8192, 65535) (ids are stored as u16)
 constexpr int MAXCHAIN = 512;          // chunks of one border the median kernel can index (15 872 points)
 constexpr int PTS_STORED = 0x40000000; // blob_d[2 bi] = last chunk | PTS_STORED, else offset into the distance scratch
-constexpr int MAXDF = 65536;           // distance scratch (double) per frame and threshold: bright blobs, fall-backs
+// distance scratch (double) per frame and threshold (bright blobs, fall-backs): RegionBuffers::maxdf = max(65536, h*w/32)
 constexpr int CH_DIRECT = 16;          // chunk ids kept with the blob record: borders up to 496 points need no chain walk
-static_assert(MAXCH <= 65536, "chunk ids are stored as u16");
 
 struct StoreVisitor {
     StatVisitor sv;
     uint32_t *pool;
     int *counter;
+    int maxch;
     unsigned short *ids;   // LDS, entry j of this lane at ids[j * 64]: the first CH_DIRECT chunks of the border
     int cur = -1, link = -1, fill = CH_PTS, nch = 0;
     int res_next = 0, res_end = 0;   // chunks reserved up front (one atomic per border in the common case)
@@ -174,7 +174,7 @@ struct StoreVisitor {
     {
         const int want = min((expected_points + CH_PTS - 1) / CH_PTS, CH_DIRECT);
         res_next = atomicAdd(counter, want);
-        res_end = min(res_next + want, MAXCH);
+        res_end = min(res_next + want, maxch);
     }
     __device__ __forceinline__ void point(int x, int y, bool vertex)
     {
@@ -183,8 +183,8 @@ struct StoreVisitor {
         if (fill == CH_PTS) {
             int c;
             if (res_next < res_end) c = res_next++;
-            else c = (sv.npts <= MAXCHAIN * CH_PTS) ? atomicAdd(counter, 1) : MAXCH;
-            if (c >= MAXCH) { ok = false; return; }
+            else c = (sv.npts <= MAXCHAIN * CH_PTS) ? atomicAdd(counter, 1) : maxch;
+            if (c >= maxch) { ok = false; return; }
             link = cur;
             cur = c;
             fill = 0;
@@ -220,21 +220,21 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
                                                    FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
                                                    int *__restrict__ blob_d_all, double *__restrict__ dists_all,
                                                    const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all,
-                                                   unsigned short *__restrict__ blob_ch_all)
+                                                   unsigned short *__restrict__ blob_ch_all, int maxch, int maxdf)
 {
     __shared__ unsigned long long s_win[BW_ROWS * 64];
     __shared__ unsigned short s_ids[CH_DIRECT * 64];
     const int f = blockIdx.y, slot = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     int *S = sw + (size_t)f * SW_STRIDE;
-    if (k >= min(S[cnt_base + slot], MAXROOTS)) return;
-    const int2 e = lists[((size_t)f * NTHR + slot) * MAXROOTS + k];
+    if (k >= min(S[cnt_base + slot], MAXSWL)) return;
+    const int2 e = lists[((size_t)f * NTHR + slot) * MAXSWL + k];
     const int root = e.x;
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
     if (e.y >= 5000) return;
     int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
-    double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXDF;
+    double *dists = dists_all + ((size_t)f * NTHR + slot) * maxdf;
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     BitWin nz{bits + ((size_t)f * NTHR + slot) * h * ws, ws, h, s_win + threadIdx.x};   // binarised = cl > 50 + 10 slot
     const int max_steps = 4 * (w + h) + 65536;
     StoreVisitor tv;
-    tv.pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
+    tv.pool = pool_all + ((size_t)f * NTHR + slot) * maxch * 32;
+    tv.maxch = maxch;
     tv.counter = &S[SW_NC + slot];
     tv.ids = s_ids + threadIdx.x;
     tv.ok = is_hole != 0;   // bright components: few are accepted, their borders are followed again instead
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     if (is_hole) tv.reserve(8 * (int)sqrtf((float)e.y) + 16);
     StatVisitor &sv = tv.sv;
     bool ok = trace_border(nz, x0, y0, is_hole != 0, tv, max_steps);
-    if (!ok) { st[f].overflow = 1; return; }
+    if (!ok) { set_overflow(st[f], OVF_TRACE); return; }
     tv.flush();
     sv.finish();
     double m00, m10, m01;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     int ix = (int)rint(cx), iy = (int)rint(cy);
     if (nz(ix, iy)) return;  // blobColor = 0: centre pixel must be dark (out-of-image cannot happen for a valid centroid)
     int bi = atomicAdd(&S[SW_NB + slot], 1);
-    if (bi >= MAXB) { st[f].overflow = 1; return; }
+    if (bi >= MAXB) { set_overflow(st[f], OVF_BLOBS); return; }
     if (tv.ok) {
         blob_d[bi * 2] = tv.cur | PTS_STORED;
         blob_d[bi * 2 + 1] = sv.npts;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
         for (int j = 0; j < min(tv.nch, CH_DIRECT); j++) ch[j] = s_ids[j * 64 + threadIdx.x];
     } else {
         int doff = atomicAdd(&S[SW_ND + slot], sv.npts);
-        if (doff + sv.npts > MAXDF) { st[f].overflow = 1; blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
+        if (doff + sv.npts > maxdf) { set_overflow(st[f], OVF_DISTS); blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
         else {
             DistVisitor dv{cx, cy, dists + doff};
             trace_border(nz, x0, y0, is_hole != 0, dv, max_steps);
@@ -324,7 +325,8 @@ __global__ void k_sw_mark_holes(int *sw, int n)
 __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
                                                     const int *__restrict__ blob_d_all, double *__restrict__ dists_all,
                                                     const uint32_t *__restrict__ pool_all,
-                                                    const unsigned short *__restrict__ blob_ch_all, FrameState *__restrict__ st)
+                                                    const unsigned short *__restrict__ blob_ch_all, FrameState *__restrict__ st,
+                                                    int maxch, int maxdf)
 {
     __shared__ double s_d[MED_LDS];
     __shared__ int s_ch[MAXCHAIN];
@@ -335,8 +337,8 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
     const int nb = part ? min(S[SW_NB + slot], MAXB) : S[SW_NA + slot];
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
-    double *dists = dists_all + ((size_t)f * NTHR + slot) * MAXDF;
-    const uint32_t *pool = pool_all + ((size_t)f * NTHR + slot) * MAXCH * 32;
+    double *dists = dists_all + ((size_t)f * NTHR + slot) * maxdf;
+    const uint32_t *pool = pool_all + ((size_t)f * NTHR + slot) * maxch * 32;
     const unsigned short *blob_ch = blob_ch_all + ((size_t)f * NTHR + slot) * MAXB * CH_DIRECT;
     for (int bi = (part ? S[SW_NA + slot] : 0) + blockIdx.x; bi < nb; bi += gridDim.x) {
         const int code = blob_d[bi * 2], n = blob_d[bi * 2 + 1];
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
             __syncthreads();
             const double cx = blobs[bi].x, cy = blobs[bi].y;
             const bool in_lds = n <= MED_LDS;
-            if (!in_lds && s_off + n > MAXDF) { if (lane == 0) st[f].overflow = 1; continue; }
+            if (!in_lds && s_off + n > maxdf) { if (lane == 0) set_overflow(st[f], OVF_DISTS); continue; }
             double *out = dists + s_off;
             for (int i = lane; i < n; i += 64) {
                 const uint32_t p = pool[(size_t)s_ch[i / CH_PTS] * 32 + i % CH_PTS];
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                         pn[lane] = gn + 1; pd[lane] = 1;
                         sX[jm] = nx; sY[jm] = ny; sR[jm] = nr;
                     }
-                    if (mine && full) S.overflow = 1;
+                    if (mine && full) set_overflow(S, OVF_GROUPS);
                     const bool fresh = mine && jm == INT_MAX;
                     const unsigned long long fb = __ballot(fresh);
                     const int gi = ng + __popcll(fb & ((1ull << lane) - 1ull));
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                             g.n = 1;
                             g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
                             sX[gi] = cx; sY[gi] = cy; sR[gi] = cr;
-                        } else S.overflow = 1;
+                        } else set_overflow(S, OVF_GROUPS);
                     }
                     ng = min(ng + __popcll(fb), MAXG);
                     if (t == 0) { s_ng = ng; s_adv = clean; }
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                                 if (lane == 0) s_mod[nm] = jm;
                                 nm++;
                             }
-                        } else if (lane == 0) S.overflow = 1;
+                        } else if (lane == 0) set_overflow(S, OVF_GROUPS);
                     } else if (ng < MAXG) {
                         if (lane == 0) {
                             Group &g = G[ng];
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                             sX[ng] = cx; sY[ng] = cy; sR[ng] = cr;
                         }
                         ng++;
-                    } else if (lane == 0) S.overflow = 1;
+                    } else if (lane == 0) set_overflow(S, OVF_GROUPS);
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (t == 0) s_ng = ng;
@@ -693,9 +695,9 @@ __global__ __launch_bounds__(64) void k_enclosed(const int2 *__restrict__ hl, co
 {
     const int f = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(sw[(size_t)f * SW_STRIDE + SW_NH + slot], MAXROOTS)) return;
+    if (k >= min(sw[(size_t)f * SW_STRIDE + SW_NH + slot], MAXSWL)) return;
     const size_t N = (size_t)h * w;
-    const int2 e = hl[((size_t)f * NTHR + slot) * MAXROOTS + k];
+    const int2 e = hl[((size_t)f * NTHR + slot) * MAXSWL + k];
     const int c = uf_find(Pfg + f * N, e.x - 1);      // bright pixel west of the hole
     atomicAdd(&encl[f * N + c], min(e.y, 5000));
 }
@@ -855,8 +857,8 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
     base = __shfl(base, leader, 64);
     if (want) {
         int k = base + __popcll(b & ((1ull << lane) - 1ull));
-        if (k < MAXROOTS) list[k].x = value;
-        else S->overflow = 1;
+        if (k < MAXSWL) list[k].x = value;
+        else set_overflow(*S, OVF_SWEEP);
     }
 }
 
@@ -897,14 +899,14 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, FrameS
                 active &= ~same;
             }
         } else if (is_root) acc[f * N + i] = 0;
-        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXROOTS, &st[f]);
+        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXSWL, &st[f]);
     }
 }
 
 // components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
 // Merged into another (DARK): hand its pixel count to the component that absorbed it.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_elem_stride,
+__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_elem_stride, int src_cap,
                                                 const int *__restrict__ src_cnt, int src_cnt_stride,
                                                 int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
                                                 int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int ns = min(src_cnt[f * src_cnt_stride], MAXROOTS);
+    const int ns = min(src_cnt[f * src_cnt_stride], src_cap);
     bool keep = false;
     int r = 0;
     if (k < ns) {
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
             if (keep) acc[f * N + r] = 0;
         }
     }
-    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXROOTS, &st[f]);
+    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXSWL, &st[f]);
 }
 
 // freeze the per-component totals of threshold slot `slot` next to the roots: the accumulator plane moves on
@@ -941,10 +943,10 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = k < min(sw[f * SW_STRIDE + cnt_base + slot], MAXROOTS);
+    const bool valid = k < min(sw[f * SW_STRIDE + cnt_base + slot], MAXSWL);
     int2 e = make_int2(0, 0);
     if (valid) {
-        int2 &g = lists[(f * NTHR + slot) * MAXROOTS + k];
+        int2 &g = lists[(f * NTHR + slot) * MAXSWL + k];
         g.y = acc[f * N + g.x];
         e = g;
     }
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
     int base = 0;
     if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
     base = __shfl(base, leader, 64);
-    if (want) trace[(f * NTHR + slot) * MAXROOTS + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
+    if (want) trace[(f * NTHR + slot) * MAXSWL + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(64) void k_region_area(const uint32_t *__restrict__
     const int ws = bit_row_words(w);
     BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
     StatVisitor sv;
-    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { st[f].overflow = 1; return; }
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
     sv.finish();
     long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;  // 2 * area, exact
     if (a2 <= 0) return;
@@ -1209,7 +1211,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXROOTS / 256, n), gtrace(MAXROOTS / 64, n, NTHR), gbk(SW_GRID, n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(MAXSWL / 64, n, NTHR), gbk(SW_GRID, n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1218,7 +1220,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_CHECK_LAUNCH("grey-level buckets");
     }
     const int per = 2 * w + 2 * h;
-    const size_t lstride = (size_t)NTHR * MAXROOTS * 2;   // ints per frame of a list array
+    const size_t lstride = (size_t)NTHR * MAXSWL * 2;   // ints per frame of a list array
     // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count)
     for (int k = 0; k < NTHR; k++) {
         const int thr = 50 + 10 * k, epoch = k + 1;
@@ -1227,7 +1229,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
             if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, s, 2)) != CPE_OK) return rc;
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.roots, (size_t)MAXROOTS, 1, (const int *)&st[0].n_roots,
+            CPE_KLAUNCH(k_sw_old<true>, dim3(MAXROOTS / 256, n), dim3(256), 0, s, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
                         (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k);
         } else {
@@ -1237,7 +1239,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, s, h, w, k, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.hl + (size_t)(k - 1) * MAXROOTS * 2, lstride, 2,
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.hl + (size_t)(k - 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k);
         }
@@ -1250,12 +1252,12 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         if (side) { (void)hipEventRecord(side->dark_done, s); (void)hipStreamWaitEvent(ts, side->dark_done, 0); }
         else if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ts, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
-                    B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
+                    B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
         CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ts, B.sw, n);
         if (side) (void)hipEventRecord(side->traced, ts);
         // their radii: still beside the bright sweep
         CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, ts, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
-                    (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st);
+                    (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
         if (side) (void)hipEventRecord(side->medians, ts);
     }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
@@ -1268,19 +1270,19 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, st, (const int *)B.bk, B.lab2, B.cnt2,
                     (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, k);
         if (j > 0)
-            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXROOTS * 2, lstride, 2,
+            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
                         (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, 0,
                         B.bl, B.sw, (int)SW_NL, k);
-        CPE_KLAUNCH(k_enclosed, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
+        CPE_KLAUNCH(k_enclosed, dim3(MAXSWL / 64, n), dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
         CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.bl, B.sw, (int)SW_NL, k, h, w, (const int *)B.cnt2, (int2 *)nullptr, st);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
     if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
-                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch);
+                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
     if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
     CPE_KLAUNCH(k_blob_median, dim3(32, n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
-                (const unsigned short *)B.blob_ch, st);
+                (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
     {
         // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
         const char *e = getenv("CPE_MERGE_REPLAY");

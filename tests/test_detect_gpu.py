@@ -76,6 +76,16 @@ def test_detect_full_size(cpe, orc, gpu):
 
 
 @pytest.mark.gpu
+def test_detect_4k_frame(cpe, orc, gpu):
+    """3840x2160 (BASELINE config 5 frame size): wider than the 2048-column LDS path of the hull kernel"""
+    from cpe_amd import synth
+    b = synth.render_batch(1, 2160, 3840, seed=17, device='cuda', with_gt=False)
+    frames = torch.cat([b['left'], b['right']]).cpu()
+    n_ok = _compare(cpe, orc, gpu, frames, allow_overflow=False)
+    assert n_ok >= 1
+
+
+@pytest.mark.gpu
 def test_detect_failure_statuses(cpe, orc, gpu):
     """frames on which the reference raises inside detect_grid: all-dark (no blob region), grid without the
     saturated spot, pure noise -- the batch is never aborted, every frame gets the oracle's status."""
