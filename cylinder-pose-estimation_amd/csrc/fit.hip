@@ -474,34 +474,12 @@ __device__ __forceinline__ double eps_of(double x)  // MATLAB eps(x)
     return ldexp(1.0, e - 53);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ X, const int *__restrict__ cnt,
-                                                     double R, double tolx, double tolf, int maxiter,
-                                                     int maxfun, double *__restrict__ o_raw,
-                                                     double *__restrict__ o_cyl, double *__restrict__ o_T,
-                                                     double *__restrict__ o_fvals, int *__restrict__ o_iters,
-                                                     int *__restrict__ o_status)
+// ---- the pieces of fitCylinderWPts3.m as device functions (one wavefront, points in LDS); k_fit_cylinder runs them on
+// all points of a frame, k_fit_ransac (build-defined, BASELINE config 5) on subsets as well
+// initial cylinder (fitCylinderWPts3.m:7-36): x0 = [origin, direction], f0 = objective at x0
+__device__ void fit_init(const double *sP, int n, double R, int lane, double *sD, int *sNb, double *x0, double &f0_out)
 {
-    __shared__ double sP[MAXP * 3];
-    __shared__ double sD[MAXP];
-    __shared__ int sNb[20];
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const int n = min(max(cnt[f], 0), MAXP);
-    if (n < 3) {
-        if (lane == 0) {
-            o_status[f] = CPE_ST_FEW_POINTS;
-            o_iters[2 * f] = 0; o_iters[2 * f + 1] = 0;
-            o_fvals[2 * f] = 0; o_fvals[2 * f + 1] = 0;
-            for (int k = 0; k < 12; k++) { o_raw[12 * f + k] = 0; o_cyl[12 * f + k] = 0; }
-            for (int k = 0; k < 16; k++) o_T[16 * f + k] = 0;
-        }
-        return;
-    }
-    const double *Xf = X + (size_t)f * MAXP * 3;
-    for (int i = lane; i < 3 * n; i += 64) sP[i] = Xf[i];
-    __syncthreads();
     Pts P{sP, n};
-
     // ctr = mean(Pts3,2); covariance; rdir = pca 3rd axis with z > 0 (fitCylinderWPts3.m:7-19)
     double ctr[3];
 #pragma unroll
@@ -624,17 +602,19 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
         for (int k = 0; k < 3; k++) dir0[k] = xx[k] * v0 + y[k] * v1;
     }
 
-    double x0[6];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         x0[c] = ctr[c] + rdir[c] * (R - d2s);
         x0[3 + c] = dir0[c];
     }
-    const double f0 = cyl_objective(x0, P, R, lane);
+    f0_out = cyl_objective(x0, P, R, lane);
+}
 
-    double xf[6], ffinal;
-    int itercount, func_evals;
-    if constexpr (MODE == 0) {
+// fminsearch (MATLAB order) from x0
+__device__ void fit_nm(const double *sP, int n, double R, int lane, double tolx, double tolf, int maxiter, int maxfun,
+                       const double *x0, double f0, double *xf, double &ffinal, int &itercount, int &func_evals)
+{
+    Pts P{sP, n};
     // ---- fminsearch (MATLAB order).  simplex is wave-uniform, kept in registers.
     constexpr int N = 6;
     double v[N + 1][N], fv[N + 1];
@@ -752,7 +732,12 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 6; k++) xf[k] = v[0][k];
     ffinal = fv[0];
-    } else {
+}
+
+__device__ void fit_lm(const double *sP, int n, double R, int lane, double tolx, double tolf, int maxiter,
+                       const double *x0, double f0, double *xf, double &ffinal, int &itercount, int &func_evals)
+{
+    Pts P{sP, n};
     // ---- Levenberg-Marquardt on the same objective (north_star's "Gauss-Newton/LM inner loop"; NOT what the
     // reference runs -- fitCylinderWPts3.m:38 uses fminsearch -- validated against the Nelder-Mead result).
     // r_i = d_i - R;  dr/do = -e/d;  dr/dv = -(alpha/d) e  with  e = (P-o) - v alpha, alpha = ((P-o).v)/|v|^2.
@@ -855,8 +840,14 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 6; k++) xf[k] = x[k];
     ffinal = fx;
-    }
+}
 
+// applyCylParamsPrior.m on both rows (ymin over the n points given), cylParams2T.m on the final row, outputs of frame f
+__device__ void fit_write(int f, int lane, const double *sP, int n, const double *x0, const double *xf, double f0, double ffinal,
+                          int itercount, int func_evals, double *__restrict__ o_raw, double *__restrict__ o_cyl,
+                          double *__restrict__ o_T, double *__restrict__ o_fvals, int *__restrict__ o_iters,
+                          int *__restrict__ o_status)
+{
     // applyCylParamsPrior.m on both rows, cylParams2T.m on the final row
     double ymin = DBL_MAX;
     for (int k = lane; k < n; k += 64) ymin = fmin(ymin, sP[3 * k + 1]);
@@ -893,6 +884,43 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
         o_iters[2 * f + 1] = func_evals;
         o_status[f] = CPE_ST_OK;
     }
+}
+
+__device__ void fit_write_few_points(int f, int lane, double *__restrict__ o_raw, double *__restrict__ o_cyl, double *__restrict__ o_T,
+                                     double *__restrict__ o_fvals, int *__restrict__ o_iters, int *__restrict__ o_status)
+{
+    if (lane == 0) {
+        o_status[f] = CPE_ST_FEW_POINTS;
+        o_iters[2 * f] = 0; o_iters[2 * f + 1] = 0;
+        o_fvals[2 * f] = 0; o_fvals[2 * f + 1] = 0;
+        for (int k = 0; k < 12; k++) { o_raw[12 * f + k] = 0; o_cyl[12 * f + k] = 0; }
+        for (int k = 0; k < 16; k++) o_T[16 * f + k] = 0;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ X, const int *__restrict__ cnt,
+                                                     double R, double tolx, double tolf, int maxiter,
+                                                     int maxfun, double *__restrict__ o_raw,
+                                                     double *__restrict__ o_cyl, double *__restrict__ o_T,
+                                                     double *__restrict__ o_fvals, int *__restrict__ o_iters,
+                                                     int *__restrict__ o_status)
+{
+    __shared__ double sP[MAXP * 3];
+    __shared__ double sD[MAXP];
+    __shared__ int sNb[20];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = min(max(cnt[f], 0), MAXP);
+    if (n < 3) { fit_write_few_points(f, lane, o_raw, o_cyl, o_T, o_fvals, o_iters, o_status); return; }
+    const double *Xf = X + (size_t)f * MAXP * 3;
+    for (int i = lane; i < 3 * n; i += 64) sP[i] = Xf[i];
+    __syncthreads();
+    double x0[6], f0, xf[6], ffinal;
+    int itercount, func_evals;
+    fit_init(sP, n, R, lane, sD, sNb, x0, f0);
+    if constexpr (MODE == 0) fit_nm(sP, n, R, lane, tolx, tolf, maxiter, maxfun, x0, f0, xf, ffinal, itercount, func_evals);
+    else fit_lm(sP, n, R, lane, tolx, tolf, maxiter, x0, f0, xf, ffinal, itercount, func_evals);
+    fit_write(f, lane, sP, n, x0, xf, f0, ffinal, itercount, func_evals, o_raw, o_cyl, o_T, o_fvals, o_iters, o_status);
 }
 
 }  // namespace
