@@ -105,6 +105,9 @@ def main():
     ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes per GPU (cycled with fresh noise)')
     ap.add_argument('--fit-mode', choices=['nm', 'lm'], default='nm',
                     help='nm = fminsearch clone (reference behaviour, default); lm = Levenberg-Marquardt fast mode')
+    ap.add_argument('--ransac', type=int, default=0, metavar='H',
+                    help='build-defined config 5: wrap the fit in a RANSAC with H hypotheses per frame (LM inside)')
+    ap.add_argument('--size', choices=['1920x1200', '3840x2160'], default='1920x1200', help='frame size (config 5 uses 3840x2160)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -116,6 +119,9 @@ def main():
     torch.cuda.set_device(dev)
     cpe_amd.lib.load()                                   # no CPU fallback: fail loudly
 
+    global H, W, BYTES_PER_FRAME
+    W, H = (int(v) for v in args.size.split('x'))
+    BYTES_PER_FRAME = 2 * (H * W + 1024 * 24)
     F = args.frames
     # ---- synthetic inputs, resident in HBM: `unique` rendered scenes, every frame gets its own sensor noise
     U = min(args.unique, F)
@@ -134,7 +140,8 @@ def main():
                 nz = nz * (torch.randint(0, 3, (k, H, W), generator=g, device=dev, dtype=torch.int16) == 0)
                 dst[i0:i0 + k] = (src[:k].to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
     pipe = pipeline.FramePipeline(H, W, K1, K2, T21, radius, chunk=args.chunk, device=dev,
-                                  fit_mode=1 if args.fit_mode == 'lm' else 0)
+                                  fit_mode=1 if (args.fit_mode == 'lm' or args.ransac) else 0,
+                                  ransac=dict(hypotheses=args.ransac, seed=2026, frame0=rank * F) if args.ransac else None)
 
     def step():
         rec = pipe.run(left, right)
@@ -190,17 +197,18 @@ def main():
         ok = ((fit_st == 0) & (dl == 0) & (dr == 0)).float().mean().item()
         total_frames = F * world * args.steps
         value = total_frames / dt
-        out = dict(metric='frames/sec (grid-detect + cylinder fit) on 1920x1200 batch', value=value, unit='frames/s',
+        out = dict(metric=f'frames/sec (grid-detect + cylinder fit) on {W}x{H} batch', value=value, unit='frames/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                    config=dict(workload=f'{F}-frame {W}x{H} stereo batch per GPU, full detect (both images) + chooseIdx + '
-                                        f'triangulate + fitCylinderWPts3 Nelder-Mead (BASELINE.json configs[2])',
+                                        f'triangulate + ' + (f'RANSAC({args.ransac} hypotheses)-wrapped LM fit (build-defined, BASELINE.json configs[4])' if args.ransac
+                                                          else f'fitCylinderWPts3 {"LM" if args.fit_mode == "lm" else "Nelder-Mead"} (BASELINE.json configs[2])'),
                                frames_per_gpu=F, chunk=args.chunk, unique_scenes=U, fit_mode=args.fit_mode,
                                parallelism=f'frames sharded x{world}, all_gather of 128-B pose records'),
                    frames_ok_fraction=ok, mean_points_per_frame=float(n_pts.float().mean().item()),
                    path_hbm_frac=value * BYTES_PER_FRAME / HBM_PEAK / world,
                    roofline=roof)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.ransac:
             m = min(12, F)
             out['cpu_baseline'] = cpu_baseline(left[:m].cpu().numpy(), right[:m].cpu().numpy(), K1, K2, T21, radius)
         print(json.dumps(out))

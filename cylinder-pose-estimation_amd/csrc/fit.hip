@@ -923,6 +923,116 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
     fit_write(f, lane, sP, n, x0, xf, f0, ffinal, itercount, func_evals, o_raw, o_cyl, o_T, o_fvals, o_iters, o_status);
 }
 
+// ---- BUILD-DEFINED (BASELINE config 5; nothing like it in the reference): RANSAC around the fit -------
+// H hypotheses per frame, one wavefront per frame.  Hypothesis 0 uses all points; hypothesis h > 0 keeps point k with
+// probability S/n, decided by a counter-based hash of (seed, frame, h, k), so every lane decides for its own points and the
+// subset does not depend on any sequential generator state.  A hypothesis = `hyp_iters` LM iterations on its subset
+// (compacted into LDS in point order) from the all-points initial cylinder, scored by the number of points with
+// | dist(point, axis) - R | < tau over ALL points; the first hypothesis with the largest count wins and the final fit
+// (Nelder-Mead or LM) runs on its inliers.  Same arithmetic, same order as oracle/src/orc_fit.c:orc_fit_cylinder_ransac.
+__device__ __forceinline__ unsigned long long ransac_hash(unsigned long long seed, unsigned long long frame, unsigned long long h,
+                                                          unsigned long long k)
+{
+    unsigned long long z = (seed ^ (frame * 0xD1B54A32D192ED03ULL) ^ (h << 32) ^ k) + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// |dist - R| < tau for point k of sP under the cylinder x
+__device__ __forceinline__ bool ransac_inlier(const double *sP, int k, const double *x, double R, double tau)
+{
+    double p2[3] = {x[0] + x[3], x[1] + x[4], x[2] + x[5]};
+    double v[3] = {p2[0] - x[0], p2[1] - x[1], p2[2] - x[2]};
+    double nv2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    return fabs(dist_pt_line(sP + 3 * k, x, v, nv2) - R) < tau;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_fit_ransac(const double *__restrict__ X, const int *__restrict__ cnt, double R, int H, int S,
+                                                   double tau, unsigned long long seed, unsigned long long frame0, int hyp_iters,
+                                                   double tolx, double tolf, int maxiter, int maxfun,
+                                                   double *__restrict__ o_raw, double *__restrict__ o_cyl, double *__restrict__ o_T,
+                                                   double *__restrict__ o_fvals, int *__restrict__ o_iters, int *__restrict__ o_status,
+                                                   int *__restrict__ o_ninl, uint8_t *__restrict__ o_mask)
+{
+    __shared__ double sP[MAXP * 3], sQ[MAXP * 3];
+    __shared__ double sD[MAXP];
+    __shared__ int sNb[20];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = min(max(cnt[f], 0), MAXP);
+    uint8_t *mk = o_mask + (size_t)f * MAXP;
+    for (int k = lane; k < MAXP; k += 64) mk[k] = 0;
+    if (n < 3) {
+        fit_write_few_points(f, lane, o_raw, o_cyl, o_T, o_fvals, o_iters, o_status);
+        if (lane == 0) o_ninl[f] = 0;
+        return;
+    }
+    const double *Xf = X + (size_t)f * MAXP * 3;
+    for (int i = lane; i < 3 * n; i += 64) sP[i] = Xf[i];
+    __syncthreads();
+    double x0[6], f0;
+    fit_init(sP, n, R, lane, sD, sNb, x0, f0);
+    const double q = (double)S / (double)n;
+    const unsigned long long frame = frame0 + (unsigned long long)f;
+    int best_cnt = -1;
+    double best_x[6] = {0, 0, 0, 0, 0, 0};
+    // keep[k] -> sQ, in point order; returns the subset size (wave-uniform)
+    auto compact = [&](auto keep) {
+        int nq = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const bool take = k < n && keep(k);
+            const unsigned long long b = __ballot(take);
+            if (take) {
+                const int pos = nq + __popcll(b & ((1ull << lane) - 1ull));
+                sQ[3 * pos] = sP[3 * k]; sQ[3 * pos + 1] = sP[3 * k + 1]; sQ[3 * pos + 2] = sP[3 * k + 2];
+            }
+            nq += __popcll(b);
+        }
+        __syncthreads();
+        return nq;
+    };
+    for (int h = 0; h < H; h++) {
+        const int nq = compact([&](int k) {
+            return h == 0 || ((double)(ransac_hash(seed, frame, (unsigned long long)h, (unsigned long long)k) >> 11) * 0x1.0p-53) < q;
+        });
+        if (nq < 6) continue;
+        double xh[6], fh;
+        int it, ev;
+        const double fq0 = cyl_objective(x0, Pts{sQ, nq}, R, lane);
+        fit_lm(sQ, nq, R, lane, tolx, tolf, hyp_iters, x0, fq0, xh, fh, it, ev);
+        int c = 0;
+        for (int k = lane; k < n; k += 64) c += ransac_inlier(sP, k, xh, R, tau) ? 1 : 0;
+        c = wave_sum_i(c);
+        if (c > best_cnt) {
+            best_cnt = c;
+#pragma unroll
+            for (int k = 0; k < 6; k++) best_x[k] = xh[k];
+        }
+    }
+    if (best_cnt < 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) best_x[k] = x0[k];
+    }
+    int nq = compact([&](int k) { return ransac_inlier(sP, k, best_x, R, tau); });
+    const int n_inl = nq;
+    if (nq < 6) {   // too few inliers to fit: all points, and say so in the mask
+        nq = compact([&](int) { return true; });
+        for (int k = lane; k < n; k += 64) mk[k] = 1;
+    } else {
+        for (int k = lane; k < n; k += 64) mk[k] = ransac_inlier(sP, k, best_x, R, tau) ? 1 : 0;
+    }
+    const double fs = cyl_objective(best_x, Pts{sQ, nq}, R, lane);
+    double xf[6], ffinal;
+    int itercount, func_evals;
+    if constexpr (MODE == 0) fit_nm(sQ, nq, R, lane, tolx, tolf, maxiter, maxfun, best_x, fs, xf, ffinal, itercount, func_evals);
+    else fit_lm(sQ, nq, R, lane, tolx, tolf, maxiter, best_x, fs, xf, ffinal, itercount, func_evals);
+    fit_write(f, lane, sQ, nq, x0, xf, f0, ffinal, itercount, func_evals, o_raw, o_cyl, o_T, o_fvals, o_iters, o_status);
+    if (lane == 0) o_ninl[f] = n_inl;
+}
+
 }  // namespace
 
 extern "C" size_t cpe_fit_workspace_bytes(int32_t n)
@@ -975,6 +1085,36 @@ extern "C" int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, i
         CPE_KLAUNCH(k_fit_cylinder<0>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
                     p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
     CPE_CHECK_LAUNCH("k_fit_cylinder");
+    return CPE_OK;
+}
+
+extern "C" int32_t cpe_fit_cylinder_ransac_batch(const double *X, const int32_t *cnt, int32_t n, double radius,
+                                                 const CpeFitParams *params, const CpeRansacParams *ransac, double *cyl_raw,
+                                                 double *cyl, double *T, double *fvals, int32_t *iters, int32_t *status,
+                                                 int32_t *n_inliers, uint8_t *inlier_mask, void *stream)
+{
+    CPE_CHECK_ARG(X && cnt && cyl_raw && cyl && T && fvals && iters && status && n_inliers && inlier_mask,
+                  "cpe_fit_cylinder_ransac_batch: null pointer");
+    CPE_CHECK_ARG(n >= 0, "cpe_fit_cylinder_ransac_batch: n < 0");
+    CpeFitParams p = {1e-5, 1e-5, 100000, 100000, CPE_FIT_LM, 0};
+    if (params) p = *params;
+    CpeRansacParams r = {64, 12, 0.5, 0, 0, 8, 0};
+    if (ransac) r = *ransac;
+    CPE_CHECK_ARG(p.tol_x >= 0 && p.tol_f >= 0 && p.max_iter > 0 && p.max_fun_evals > 0, "cpe_fit_cylinder_ransac_batch: bad CpeFitParams");
+    CPE_CHECK_ARG(p.mode == CPE_FIT_NELDER_MEAD || p.mode == CPE_FIT_LM, "cpe_fit_cylinder_ransac_batch: unknown mode %d", p.mode);
+    CPE_CHECK_ARG(r.hypotheses >= 1 && r.hypotheses <= 4096 && r.sample >= 6 && r.tau > 0 && r.hyp_iters >= 1,
+                  "cpe_fit_cylinder_ransac_batch: bad CpeRansacParams (hypotheses 1..4096, sample >= 6, tau > 0, hyp_iters >= 1)");
+    if (n == 0) return CPE_OK;
+    CPE_LAUNCH_BEGIN();
+    if (p.mode == CPE_FIT_LM)
+        CPE_KLAUNCH(k_fit_ransac<1>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, r.hypotheses, r.sample, r.tau,
+                    (unsigned long long)r.seed, (unsigned long long)r.frame0, r.hyp_iters, p.tol_x, p.tol_f, p.max_iter, p.max_fun_evals,
+                    cyl_raw, cyl, T, fvals, iters, status, n_inliers, inlier_mask);
+    else
+        CPE_KLAUNCH(k_fit_ransac<0>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, r.hypotheses, r.sample, r.tau,
+                    (unsigned long long)r.seed, (unsigned long long)r.frame0, r.hyp_iters, p.tol_x, p.tol_f, p.max_iter, p.max_fun_evals,
+                    cyl_raw, cyl, T, fvals, iters, status, n_inliers, inlier_mask);
+    CPE_CHECK_LAUNCH("k_fit_ransac");
     return CPE_OK;
 }
 

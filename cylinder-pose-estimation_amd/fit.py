@@ -88,11 +88,36 @@ def fit_cylinder_batch(pts3, cnt, radius, tol_x=1e-5, tol_f=1e-5, max_iter=10000
     return dict(cyl_raw=raw, cyl=cyl, T=T, fvals=fv, iters=it, status=st)
 
 
+def fit_cylinder_ransac_batch(pts3, cnt, radius, hypotheses=64, sample=12, tau=0.5, seed=0, frame0=0, hyp_iters=8, tol_x=1e-5,
+                              tol_f=1e-5, max_iter=100000, max_fun_evals=100000, mode=FIT_LM):
+    """BUILD-DEFINED (BASELINE config 5; the reference has no RANSAC): the fit wrapped in a consensus search, see
+    include/cpe.h cpe_fit_cylinder_ransac_batch.  Extra outputs: n_inliers i32[n], inlier_mask u8[n,MAXP]."""
+    L = _lib.load()
+    dev = pts3.device
+    n = cnt.shape[0]
+    raw = torch.zeros((n, 2, 6), dtype=torch.float64, device=dev); cyl = torch.zeros_like(raw)
+    T = torch.zeros((n, 4, 4), dtype=torch.float64, device=dev)
+    fv = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    it = torch.zeros((n, 2), dtype=torch.int32, device=dev); st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ninl = torch.zeros(n, dtype=torch.int32, device=dev); mask = torch.zeros((n, _lib.MAXP), dtype=torch.uint8, device=dev)
+    prm = _lib.CpeFitParams(tol_x, tol_f, max_iter, max_fun_evals, mode, 0)
+    rp = _lib.CpeRansacParams(hypotheses, sample, tau, seed, frame0, hyp_iters, 0)
+    _lib.check(L.cpe_fit_cylinder_ransac_batch(pts3.data_ptr(), cnt.data_ptr(), n, float(radius), C.addressof(prm), C.addressof(rp),
+                                               raw.data_ptr(), cyl.data_ptr(), T.data_ptr(), fv.data_ptr(), it.data_ptr(),
+                                               st.data_ptr(), ninl.data_ptr(), mask.data_ptr(), _stream()),
+               'cpe_fit_cylinder_ransac_batch')
+    return dict(cyl_raw=raw, cyl=cyl, T=T, fvals=fv, iters=it, status=st, n_inliers=ninl, inlier_mask=mask)
+
+
 def fit_single_cylinder_batch(gp1: GridTables, gp2: GridTables, K1, K2, T21, radius, selector=SEL_CHOOSE_IDX,
-                              patch=3, th=0.3, **fit_kw):
-    """[pts3, cylT, fvals, meanError] = fitSingleCylinder(...) for every frame of the batch."""
+                              patch=3, th=0.3, ransac=None, **fit_kw):
+    """[pts3, cylT, fvals, meanError] = fitSingleCylinder(...) for every frame of the batch.
+    ransac: None (reference behaviour) or a dict of fit_cylinder_ransac_batch keywords (build-defined config 5)."""
     sel = select_triangulate_batch(gp1, gp2, K1, K2, T21, selector, patch, th)
-    fit = fit_cylinder_batch(sel['pts3'], sel['m'], radius, **fit_kw)
+    if ransac is not None:
+        fit = fit_cylinder_ransac_batch(sel['pts3'], sel['m'], radius, **ransac, **fit_kw)
+    else:
+        fit = fit_cylinder_batch(sel['pts3'], sel['m'], radius, **fit_kw)
     out = dict(sel)
     out.update(fit)
     return out

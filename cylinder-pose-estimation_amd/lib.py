@@ -40,6 +40,8 @@ _SIGS = {
     'cpe_select_triangulate_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 +
                                      [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
     'cpe_multi_frame_terms': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    'cpe_fit_cylinder_ransac_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p] +
+                                      [C.c_void_p] * 9),
     'cpe_undistort_map': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cpe_remap_bilinear_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cpe_fit_cylinder_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p] +
@@ -54,6 +56,11 @@ class CpeDetectParams(C.Structure):
 class CpeFitParams(C.Structure):
     _fields_ = [('tol_x', C.c_double), ('tol_f', C.c_double), ('max_iter', C.c_int32), ('max_fun_evals', C.c_int32),
                 ('mode', C.c_int32), ('reserved', C.c_int32)]
+
+
+class CpeRansacParams(C.Structure):
+    _fields_ = [('hypotheses', C.c_int32), ('sample', C.c_int32), ('tau', C.c_double), ('seed', C.c_uint64),
+                ('frame0', C.c_uint64), ('hyp_iters', C.c_int32), ('reserved', C.c_int32)]
 
 
 MAXP = 1024

@@ -31,10 +31,11 @@ class FramePipeline:
     """reusable workspaces for chunks of `chunk` stereo frames of size h x w"""
 
     def __init__(self, h, w, K1, K2, T21, radius, chunk=64, device='cuda:0', selector=fit.SEL_CHOOSE_IDX, th=0.3,
-                 fit_mode=fit.FIT_NELDER_MEAD, lanes=1):
+                 fit_mode=fit.FIT_NELDER_MEAD, lanes=1, ransac=None):
         self.h, self.w, self.chunk, self.device = h, w, chunk, torch.device(device)
         self.K1, self.K2, self.T21, self.radius = K1, K2, T21, radius
         self.selector, self.th, self.fit_mode = selector, th, fit_mode
+        self.ransac = ransac            # None, or keywords of fit.fit_cylinder_ransac_batch (build-defined config 5)
         self.ws = {}
         # chunks are independent: `lanes` of them are in flight on their own HIP streams (each with its own
         # workspace), so the serial tails of one chunk (blob grouping, line fitting: one workgroup per frame)
@@ -47,14 +48,15 @@ class FramePipeline:
             self.ws[(lane, n_img)] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
         return self.ws[(lane, n_img)]
 
-    def run_chunk(self, left, right, lane=0):
+    def run_chunk(self, left, right, lane=0, frame0=0):
         c = left.shape[0]
         frames = torch.cat([left, right])                 # [2c,h,w]: one detect call for both cameras
         det = api.detect_grid_batch(frames, self._ws(2 * c, lane))
         g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
         g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
+        rk = None if self.ransac is None else dict(self.ransac, frame0=int(self.ransac.get('frame0', 0)) + frame0)
         out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th,
-                                            mode=self.fit_mode)
+                                            ransac=rk, mode=self.fit_mode)
         rec = torch.empty((c, REC), dtype=torch.float64, device=frames.device)
         rec[:, 0:6] = out['cyl'][:, 0]
         rec[:, 6:12] = out['cyl'][:, 1]
@@ -71,7 +73,7 @@ class FramePipeline:
         if self.lanes == 1 or n_chunks == 1 or left.device.type != 'cuda':
             for i0 in range(0, F, self.chunk):
                 i1 = min(F, i0 + self.chunk)
-                recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1])[0]
+                recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1], 0, i0)[0]
             return recs
         if self._streams is None:
             self._streams = [torch.cuda.Stream(device=left.device) for _ in range(self.lanes)]
@@ -82,7 +84,7 @@ class FramePipeline:
             i1 = min(F, i0 + self.chunk)
             lane = k % self.lanes
             with torch.cuda.stream(self._streams[lane]):
-                recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1], lane)[0]
+                recs[i0:i1] = self.run_chunk(left[i0:i1], right[i0:i1], lane, i0)[0]
         for st in self._streams:
             main.wait_stream(st)
         return recs

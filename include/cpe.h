@@ -189,6 +189,27 @@ CPE_API int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, int3
                                        const CpeFitParams *params, double *cyl_raw, double *cyl, double *T,
                                        double *fvals, int32_t *iters, int32_t *status, void *stream);
 
+/* BUILD-DEFINED extension (BASELINE.json configs[4] "RANSAC-wrapped fitSingleCylinder"; the reference has no RANSAC):
+ * per frame, `hypotheses` LM fits (`hyp_iters` iterations each) on random subsets -- hypothesis 0 = all points, the others
+ * keep a point with probability sample / count, decided by a counter-based hash of (seed, frame0 + frame, hypothesis, point)
+ * -- scored by the number of points with |dist(point, axis) - radius| < tau; the final fit (`params->mode`) runs on the
+ * inliers of the best hypothesis.  Outputs as cpe_fit_cylinder_batch (cyl_raw row 0 = the all-points initial cylinder,
+ * fvals[0] = objective there, fvals[1] = objective of the final fit over the inliers) plus
+ *   n_inliers i32[n], inlier_mask u8[n,CPE_MAXP] (1 = used by the final fit). */
+typedef struct {
+    int32_t hypotheses;   /* default 64 */
+    int32_t sample;       /* expected subset size, default 12 (>= 6) */
+    double tau;           /* inlier band around the radius, same unit as the points, default 0.5 */
+    uint64_t seed;
+    uint64_t frame0;      /* global index of frame 0 of this call (shards of one batch get different streams) */
+    int32_t hyp_iters;    /* LM iterations per hypothesis, default 8 */
+    int32_t reserved;
+} CpeRansacParams;
+CPE_API int32_t cpe_fit_cylinder_ransac_batch(const double *X, const int32_t *cnt, int32_t n, double radius,
+                                              const CpeFitParams *params, const CpeRansacParams *ransac, double *cyl_raw,
+                                              double *cyl, double *T, double *fvals, int32_t *iters, int32_t *status,
+                                              int32_t *n_inliers, uint8_t *inlier_mask, void *stream);
+
 /* Row f-3: the undistortion pre-step of the CLI entry point, utils/iotool.py:22-39
  *   undistort_image(image, camera_params) = cv2.undistort(image, IntrinsicMatrix, hstack(Radial, Tangential))
  * cv2.undistort rebuilds its fixed-point map per image; here the map is built once per camera and applied per frame.

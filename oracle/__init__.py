@@ -144,6 +144,19 @@ def fit_cylinder(P, R, tolx=1e-5, tolf=1e-5, maxiter=100000, maxfun=100000, mode
     return dict(cyl0=cyl0, cyl=cyl, fvals=fv, iters=it.value, evals=ev.value, status=st)
 
 
+def fit_cylinder_ransac(P, R, hypotheses=64, sample=12, tau=0.5, seed=0, frame=0, hyp_iters=8, tolx=1e-5, tolf=1e-5,
+                        maxiter=100000, maxfun=100000, mode=1):
+    """BUILD-DEFINED RANSAC around the fit (orc_fit_cylinder_ransac): -> dict(cyl0, cyl (raw), fvals, iters, evals, n_inliers, mask, status)"""
+    P = _f64(P)
+    cyl0 = np.empty(6); cyl = np.empty(6); fv = np.empty(2); it = C.c_int(0); ev = C.c_int(0); ni = C.c_int(0)
+    mask = np.zeros(len(P), dtype=np.uint8)
+    st = lib().orc_fit_cylinder_ransac(_p(P, C.c_double), len(P), C.c_double(R), hypotheses, sample, C.c_double(tau),
+                                       C.c_uint64(seed), C.c_uint64(frame), hyp_iters, C.c_double(tolx), C.c_double(tolf), maxiter,
+                                       maxfun, mode, _p(cyl0, C.c_double), _p(cyl, C.c_double), _p(fv, C.c_double), C.byref(it),
+                                       C.byref(ev), C.byref(ni), _p(mask, C.c_uint8))
+    return dict(cyl0=cyl0, cyl=cyl, fvals=fv, iters=it.value, evals=ev.value, n_inliers=ni.value, mask=mask, status=st)
+
+
 def apply_prior(cyl, P):
     cyl = _f64(cyl).copy(); P = _f64(P)
     lib().orc_apply_prior(_p(cyl, C.c_double), _p(P, C.c_double), len(P))

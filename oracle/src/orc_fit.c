@@ -703,10 +703,9 @@ ORC_API int orc_fit_cylinder_mode(const double *P, int n, double R, double tolx,
     return fit_cylinder_mode(P, n, R, tolx, tolf, maxiter, maxfun, mode, cyl0, cyl, fvals, iters, evals);
 }
 
-static int fit_cylinder_mode(const double *P, int n, double R, double tolx, double tolf, int maxiter, int maxfun,
-                             int mode, double *cyl0, double *cyl, double *fvals, int *iters, int *evals)
+/* initial cylinder of fitCylinderWPts3.m:7-36 and the objective there */
+static void fit_init(const double *P, int n, double R, double *cyl0, double *f0)
 {
-    if (n < 3) return 5;
     double *tmp = (double *)malloc((size_t)(n + 1) * sizeof(double));
     double ctr[3];
     for (int c = 0; c < 3; c++) {
@@ -736,10 +735,83 @@ static int fit_cylinder_mode(const double *P, int n, double R, double tolx, doub
         cyl0[c] = ctr[c] + rdir[c] * (R - d2s);
         cyl0[3 + c] = dir0[c];
     }
-    fvals[0] = cyl_objective(cyl0, P, n, R, tmp);
+    *f0 = cyl_objective(cyl0, P, n, R, tmp);
+    free(tmp);
+}
+
+static int fit_cylinder_mode(const double *P, int n, double R, double tolx, double tolf, int maxiter, int maxfun,
+                             int mode, double *cyl0, double *cyl, double *fvals, int *iters, int *evals)
+{
+    if (n < 3) return 5;
+    fit_init(P, n, R, cyl0, &fvals[0]);
     if (mode == 1) lm6(cyl0, fvals[0], P, n, R, tolx, tolf, maxiter, cyl, &fvals[1], iters, evals);
     else nelder_mead6(cyl0, P, n, R, tolx, tolf, maxiter, maxfun, cyl, &fvals[1], iters, evals);
-    free(tmp);
+    return 0;
+}
+
+/* ---- BUILD-DEFINED (no counterpart in the reference; BASELINE config 5 / SURVEY 7.8): RANSAC around the fit ----------
+ * H hypotheses per frame.  Hypothesis 0 uses all points; hypothesis h > 0 keeps point k with probability S/n, decided by
+ * a counter-based hash of (seed, frame, h, k) -- no sequential generator state, so every lane / thread decides for its
+ * own points.  Each hypothesis: `hyp_iters` LM iterations from the all-points initial cylinder on its subset, then the
+ * inlier count | dist(point, axis) - R | < tau over ALL points.  The first hypothesis with the largest count wins;
+ * the final fit (mode: 0 Nelder-Mead, 1 LM) runs on its inliers from its parameters.  Subsets / inlier sets of fewer
+ * than 6 points are skipped / replaced by all points. */
+static uint64_t ransac_hash(uint64_t seed, uint64_t frame, uint64_t h, uint64_t k)
+{
+    uint64_t z = (seed ^ (frame * 0xD1B54A32D192ED03ULL) ^ (h << 32) ^ k) + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+ORC_API int orc_fit_cylinder_ransac(const double *P, int n, double R, int H, int S, double tau, uint64_t seed, uint64_t frame,
+                                    int hyp_iters, double tolx, double tolf, int maxiter, int maxfun, int mode, double *cyl0,
+                                    double *cyl, double *fvals, int *iters, int *evals, int *n_inl, uint8_t *mask)
+{
+    if (n < 3) return 5;
+    double *Q = (double *)malloc((size_t)(n + 1) * 3 * sizeof(double)), *d = (double *)malloc((size_t)(n + 1) * sizeof(double));
+    fit_init(P, n, R, cyl0, &fvals[0]);
+    const double q = (double)S / (double)n;
+    int best_cnt = -1;
+    double best_x[6] = {0, 0, 0, 0, 0, 0};
+    for (int h = 0; h < H; h++) {
+        int nq = 0;
+        for (int k = 0; k < n; k++) {
+            int take = 1;
+            if (h > 0) take = ((double)(ransac_hash(seed, frame, (uint64_t)h, (uint64_t)k) >> 11) * 0x1.0p-53) < q;
+            if (take) { Q[3 * nq] = P[3 * k]; Q[3 * nq + 1] = P[3 * k + 1]; Q[3 * nq + 2] = P[3 * k + 2]; nq++; }
+        }
+        if (nq < 6) continue;
+        double xh[6], fh, fq0 = cyl_objective(cyl0, Q, nq, R, d);
+        int it, ev;
+        lm6(cyl0, fq0, Q, nq, R, tolx, tolf, hyp_iters, xh, &fh, &it, &ev);
+        double p2[3] = {xh[0] + xh[3], xh[1] + xh[4], xh[2] + xh[5]};
+        dist_to_line(P, n, xh, p2, d);
+        int c = 0;
+        for (int k = 0; k < n; k++) c += fabs(d[k] - R) < tau;
+        if (c > best_cnt) { best_cnt = c; memcpy(best_x, xh, sizeof best_x); }
+    }
+    if (best_cnt < 0) { best_cnt = 0; memcpy(best_x, cyl0, sizeof best_x); }   /* no hypothesis had 6 points */
+    int nq = 0;
+    {
+        double p2[3] = {best_x[0] + best_x[3], best_x[1] + best_x[4], best_x[2] + best_x[5]};
+        dist_to_line(P, n, best_x, p2, d);
+        for (int k = 0; k < n; k++) {
+            mask[k] = fabs(d[k] - R) < tau;
+            if (mask[k]) { Q[3 * nq] = P[3 * k]; Q[3 * nq + 1] = P[3 * k + 1]; Q[3 * nq + 2] = P[3 * k + 2]; nq++; }
+        }
+    }
+    *n_inl = nq;
+    if (nq < 6) {   /* too few inliers to fit: all points, and say so in the mask */
+        memcpy(Q, P, (size_t)n * 3 * sizeof(double));
+        nq = n;
+        for (int k = 0; k < n; k++) mask[k] = 1;
+    }
+    double fs = cyl_objective(best_x, Q, nq, R, d);
+    if (mode == 1) lm6(best_x, fs, Q, nq, R, tolx, tolf, maxiter, cyl, &fvals[1], iters, evals);
+    else nelder_mead6(best_x, Q, nq, R, tolx, tolf, maxiter, maxfun, cyl, &fvals[1], iters, evals);
+    /* applyCylParamsPrior / cylParams2T are applied by the caller on the points of the final fit (Q) */
+    free(Q); free(d);
     return 0;
 }
 
