@@ -74,25 +74,32 @@ def pmc_traffic(kernel, images_per_launch):
     return None
 
 
-def cpu_baseline(left, right, K1, K2, T21, radius, budget_s=20.0):
-    """the oracle (single-thread C restatement of the reference path) timed on this host: kind = "port" """
+def cpu_baseline(left, right, K1, K2, T21, radius, gpu_rec=None, fit_mode=0, budget_s=20.0):
+    """the oracle (single-thread C restatement of the reference path) timed on this host: kind = "port".
+    gpu_rec: the GPU pose records of the same frames -> max |pose difference| (the second half of BASELINE's metric)"""
     import oracle
     from oracle import stages as S
     oracle.build()
     n = 0
+    dmax = 0.0
     t0 = time.time()
     while n < left.shape[0]:
         a = S.detect_grid(left[n]); b = S.detect_grid(right[n])
         if a['status'] == 0 and b['status'] == 0:
             gp1 = np.concatenate([a['xy'], a['id']], 1); gp2 = np.concatenate([b['xy'], b['id']], 1)
-            oracle.fit_single_cylinder(gp1, gp2, K1, K2, T21, radius)
+            ref = oracle.fit_single_cylinder(gp1, gp2, K1, K2, T21, radius)
+            if gpu_rec is not None and fit_mode == 0 and ref['status'] == 0:
+                dmax = max(dmax, float(np.abs(gpu_rec[n, 0:12].reshape(2, 6) - ref['cyl']).max()))
         n += 1
         if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
-    return dict(value=n / dt, unit='frames/s', cores=1, kind='port',
-                sample=f'{n} stereo frames {W}x{H} of the same synthetic workload, oracle detect_grid x2 + fitSingleCylinder, '
-                       f'one thread, {dt:.1f} s')
+    out = dict(value=n / dt, unit='frames/s', cores=1, kind='port',
+               sample=f'{n} stereo frames {W}x{H} of the same synthetic workload, oracle detect_grid x2 + fitSingleCylinder, '
+                      f'one thread, {dt:.1f} s')
+    if gpu_rec is not None and fit_mode == 0:
+        out['max_abs_dpose_gpu_vs_port'] = dmax     # cylinder origin / direction (2 x 6) of the same frames; 0.0 = bit-identical
+    return out
 
 
 def main():
@@ -210,7 +217,8 @@ def main():
                    roofline=roof)
         if not args.no_cpu_baseline and not args.ransac:
             m = min(12, F)
-            out['cpu_baseline'] = cpu_baseline(left[:m].cpu().numpy(), right[:m].cpu().numpy(), K1, K2, T21, radius)
+            out['cpu_baseline'] = cpu_baseline(left[:m].cpu().numpy(), right[:m].cpu().numpy(), K1, K2, T21, radius,
+                                               gpu_rec=allrec[:m].cpu().numpy(), fit_mode=1 if args.fit_mode == 'lm' else 0)
         print(json.dumps(out))
     D.barrier()
 
