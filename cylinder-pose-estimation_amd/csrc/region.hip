@@ -283,26 +283,88 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     b.key = root;   // discovery position of the border in the raster scan
 }
 
-// d[(n-1)/2] and d[n/2] of the sorted distances by rank counting (ties broken by index: every rank occurs once)
-template <class Ptr>
-__device__ __forceinline__ double median_of(Ptr d, int n, int lane)
+// k-th smallest (0-based) of n values read through get(i) by one wavefront, for any n: the candidate set is narrowed by
+// 64-bucket histograms (monotone bucket map over [min, max] of the candidates; the members of one bucket are exactly
+// the candidates between that bucket's smallest and largest member) until at most SEL_CAP candidates are left, which
+// are then ranked against each other in LDS.  O(n) reads per level, usually two levels.
+constexpr int SEL_CAP = 256;
+template <class Get>
+__device__ double wave_select(Get get, int n, int k, int lane, double *s_buf /* SEL_CAP */, int *s_hist /* 64 */, int *s_cnt)
+{
+    double lo = -1e300, hi = 1e300;   // candidates: lo <= v <= hi
+    for (;;) {
+        double mn = 1e300, mx = -1e300;
+        int cnt = 0, below = 0;
+        for (int i = lane; i < n; i += 64) {
+            const double v = get(i);
+            if (v < lo) below++;
+            else if (v <= hi) { cnt++; mn = fmin(mn, v); mx = fmax(mx, v); }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
+            cnt += __shfl_xor(cnt, off, 64); below += __shfl_xor(below, off, 64);
+        }
+        const int kk = k - below;   // rank among the candidates
+        if (mx == mn) return mn;
+        __syncthreads();
+        if (cnt <= SEL_CAP) {
+            if (lane == 0) *s_cnt = 0;
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const double v = get(i);
+                if (v >= lo && v <= hi) s_buf[atomicAdd(s_cnt, 1)] = v;
+            }
+            __syncthreads();
+            double found = -1e300;
+            for (int j = lane; j < cnt; j += 64) {
+                const double x = s_buf[j];
+                int less = 0, leq = 0;
+                for (int q = 0; q < cnt; q++) { const double y = s_buf[q]; less += (y < x) ? 1 : 0; leq += (y <= x) ? 1 : 0; }
+                if (less <= kk && kk < leq) found = x;
+            }
+            for (int off = 32; off >= 1; off >>= 1) found = fmax(found, __shfl_xor(found, off, 64));
+            return found;
+        }
+        const double scale = 64.0 / (mx - mn);
+        s_hist[lane] = 0;
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) {
+            const double v = get(i);
+            if (v >= lo && v <= hi) atomicAdd(&s_hist[min(63, (int)((v - mn) * scale))], 1);
+        }
+        __syncthreads();
+        const int hc = s_hist[lane];
+        int incl = hc;
+        for (int off = 1; off < 64; off <<= 1) { int tt = __shfl_up(incl, off, 64); if (lane >= off) incl += tt; }
+        const int bstar = __popcll(__ballot(incl <= kk));
+        // the bucket's members: candidates whose bucket index is bstar = the candidates between its extreme members
+        double nlo = 1e300, nhi = -1e300;
+        for (int i = lane; i < n; i += 64) {
+            const double v = get(i);
+            if (v >= lo && v <= hi && min(63, (int)((v - mn) * scale)) == bstar) { nlo = fmin(nlo, v); nhi = fmax(nhi, v); }
+        }
+        for (int off = 32; off >= 1; off >>= 1) { nlo = fmin(nlo, __shfl_xor(nlo, off, 64)); nhi = fmax(nhi, __shfl_xor(nhi, off, 64)); }
+        lo = nlo; hi = nhi;
+    }
+}
+
+// (d[(n-1)/2] + d[n/2]) / 2 of the sorted values
+template <class Get>
+__device__ double wave_median(Get get, int n, int lane, double *s_buf, int *s_hist, int *s_cnt)
 {
     const int k1 = (n - 1) / 2, k2 = n / 2;
-    double v1 = 0, v2 = 0;
-    for (int i = lane; i < n; i += 64) {
-        double di = d[i];
-        int rank = 0;
-        for (int j = 0; j < n; j++) {
-            double dj = d[j];
-            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+    const double v1 = wave_select(get, n, k1, lane, s_buf, s_hist, s_cnt);
+    double v2 = v1;
+    if (k2 != k1) {
+        int le = 0;
+        double nxt = 1e300;
+        for (int i = lane; i < n; i += 64) {
+            const double v = get(i);
+            if (v <= v1) le++;
+            else nxt = fmin(nxt, v);
         }
-        if (rank == k1) v1 = di;
-        if (rank == k2) v2 = di;
-    }
-    // exactly one lane holds each value
-    for (int off = 32; off >= 1; off >>= 1) {
-        v1 = fmax(v1, __shfl_xor(v1, off, 64));
-        v2 = fmax(v2, __shfl_xor(v2, off, 64));
+        for (int off = 32; off >= 1; off >>= 1) { le += __shfl_xor(le, off, 64); nxt = fmin(nxt, __shfl_xor(nxt, off, 64)); }
+        if (le <= k2) v2 = nxt;   // the (k2)-th value is the next larger one
     }
     return (v1 + v2) / 2.;
 }
@@ -312,7 +374,6 @@ __device__ __forceinline__ double median_of(Ptr d, int n, int lane)
 // Common case (border of up to 496 points, ids of its chunks in the blob record): the squared distances stay in
 // registers, a 64-bucket histogram over [min, max] (monotone bucket map) finds the bucket that holds rank k, and only
 // that bucket's few members are compared with each other -- O(n) instead of the O(n^2) rank count of the general path.
-constexpr int MED_LDS = 1024;
 constexpr int MED_FAST = CH_DIRECT * CH_PTS;
 __global__ void k_sw_mark_holes(int *sw, int n)
 {
@@ -328,10 +389,10 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
                                                     const unsigned short *__restrict__ blob_ch_all, FrameState *__restrict__ st,
                                                     int maxch, int maxdf)
 {
-    __shared__ double s_d[MED_LDS];
+    __shared__ double s_d[MED_FAST > SEL_CAP ? MED_FAST : SEL_CAP];
     __shared__ int s_ch[MAXCHAIN];
     __shared__ int s_hist[64];
-    __shared__ int s_off, s_cnt;
+    __shared__ int s_cnt;
     const int f = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
     int *S = sw + (size_t)f * SW_STRIDE;
     const int nb = part ? min(S[SW_NB + slot], MAXB) : S[SW_NA + slot];
@@ -406,30 +467,24 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
             }
             r = (sqrt(res[0]) + sqrt(res[1])) / 2.;
         } else if (code & PTS_STORED) {
+            // long border (> 496 points): chunk ids by walking the chain, distances recomputed from the points on every read
             const int nch = (n + CH_PTS - 1) / CH_PTS;   // <= MAXCHAIN (StoreVisitor stops storing beyond that)
             __syncthreads();
             if (lane == 0) {
                 int c = code & (PTS_STORED - 1);
                 for (int j = nch - 1; j >= 0; j--) { s_ch[j] = c; c = (int)pool[(size_t)c * 32 + 31]; }
-                s_off = 0;
-                if (n > MED_LDS) s_off = atomicAdd(&S[SW_ND + slot], n);
             }
             __syncthreads();
             const double cx = blobs[bi].x, cy = blobs[bi].y;
-            const bool in_lds = n <= MED_LDS;
-            if (!in_lds && s_off + n > maxdf) { if (lane == 0) set_overflow(st[f], OVF_DISTS); continue; }
-            double *out = dists + s_off;
-            for (int i = lane; i < n; i += 64) {
+            auto get = [&](int i) {
                 const uint32_t p = pool[(size_t)s_ch[i / CH_PTS] * 32 + i % CH_PTS];
                 const double dx = cx - (double)(int)(p & 0xFFFFu), dy = cy - (double)(int)(p >> 16);
-                const double vv = sqrt(dx * dx + dy * dy);
-                if (in_lds) s_d[i] = vv;
-                else out[i] = vv;
-            }
-            __syncthreads();
-            r = in_lds ? median_of((const double *)s_d, n, lane) : median_of((const double *)out, n, lane);
+                return sqrt(dx * dx + dy * dy);
+            };
+            r = wave_median(get, n, lane, s_d, s_hist, &s_cnt);
         } else {
-            r = median_of((const double *)(dists + code), n, lane);
+            const double *dd = dists + code;   // border followed a second time (bright components, pool overflow)
+            r = wave_median([&](int i) { return dd[i]; }, n, lane, s_d, s_hist, &s_cnt);
         }
         if (lane == 0) blobs[bi].r = r;
     }
