@@ -316,13 +316,46 @@ __global__ __launch_bounds__(256) void k_bitplanes(const uint8_t *__restrict__ i
     }
 }
 
+// single plane (mask != 0 / image > thr): one thread per 8 pixels = one byte of the plane (pixel x is bit (x + 32) of its
+// row, so byte 4 + x / 8 holds pixels 8 (x / 8) .. + 7), 64 consecutive bytes per wavefront
+__global__ __launch_bounds__(256) void k_bitplane1(const uint8_t *__restrict__ img, int rows_total, int w, int thr,
+                                                   uint32_t *__restrict__ plane)
+{
+    const int ws = bit_row_words(w), wb = ws * 4;             // bytes per plane row
+    const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= (long long)rows_total * wb) return;
+    const int row = (int)(gi / wb), j = (int)(gi - (long long)row * wb);
+    const int x0 = (j - 4) * 8;
+    unsigned b = 0;
+    if (j >= 4 && x0 < w) {
+        const uint8_t *p = img + (size_t)row * w + x0;
+        if (x0 + 8 <= w && ((((size_t)p) & 3) == 0)) {
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(p), c = *reinterpret_cast<const uint32_t *>(p + 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                b |= ((int)((a >> (8 * k)) & 255u) > thr ? 1u : 0u) << k;
+                b |= ((int)((c >> (8 * k)) & 255u) > thr ? 1u : 0u) << (4 + k);
+            }
+        } else {
+            for (int k = 0; k < 8 && x0 + k < w; k++) b |= ((int)p[k] > thr ? 1u : 0u) << k;
+        }
+    }
+    reinterpret_cast<uint8_t *>(plane)[(size_t)row * wb + j] = (uint8_t)b;
+}
+
 }  // namespace
 
 int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step, int nplanes, uint32_t *planes, hipStream_t s)
 {
     CPE_CHECK_ARG(nplanes >= 1 && nplanes <= 64, "build_bitplanes: 1..64 planes");
-    const long long waves = (long long)n * h * ((w + 63) >> 6);
     CPE_LAUNCH_BEGIN();
+    if (nplanes == 1) {
+        const long long bytes = (long long)n * h * bit_row_words(w) * 4;
+        CPE_KLAUNCH(k_bitplane1, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, s, img, n * h, w, thr0, planes);
+        CPE_CHECK_LAUNCH("k_bitplane1");
+        return CPE_OK;
+    }
+    const long long waves = (long long)n * h * ((w + 63) >> 6);
     CPE_KLAUNCH(k_bitplanes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, img, n * h, h, w, thr0, step, nplanes, planes);
     CPE_CHECK_LAUNCH("k_bitplanes");
     return CPE_OK;

@@ -32,3 +32,7 @@ for s, e, k in byq[mainq]:
 print(f'main queue {mainq}: idle gaps between its kernels {gaps / 1e6:.2f} ms')
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
     print(f'   {k:28s} x{v[0]:3d} {v[1] / 1e6:7.3f} ms')
+print('--- kernels longer than 0.8 ms, in start order (q = queue)')
+for s, e, q, k in call:
+    if (e - s) / 1e6 > 0.8:
+        print(f'  q{q} {short(k):26s} start {(s - t0) / 1e6:7.2f} dur {(e - s) / 1e6:6.2f}')
