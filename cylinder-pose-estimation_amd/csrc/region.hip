@@ -87,34 +87,63 @@ __global__ __launch_bounds__(256) void k_clahe_lut(unsigned int *__restrict__ hi
     lut[(size_t)blockIdx.x * 256 + t] = (uint8_t)sat_u8((int)rintf((float)sh[t] * g.lutScale));
 }
 
-__global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ gray, size_t total, int h, int w,
+// grid = (ceil(N / 4096), n), 16 pixels per thread.  Also accumulates the bounding box of the result's pixels > 50 (the
+// lowest threshold of the blob detector) in nrect[f]: the working rectangle of the whole sweep comes with the pass that
+// writes the image.  (4096 pixels per workgroup keep the same-address atomics on the box rare.)
+__global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ gray, int h, int w,
                                                      ClaheGeom g, const uint8_t *__restrict__ lut,
-                                                     uint8_t *__restrict__ dst)
+                                                     uint8_t *__restrict__ dst, int *__restrict__ nrect)
 {
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total) return;
-    size_t N = (size_t)h * w;
-    size_t f = gi / N;
-    int i = (int)(gi - f * N);
-    int y = i / w, x = i - y * w;
-    float inv_tw = 1.0f / g.tw, inv_th = 1.0f / g.th;
-    float tyf = y * inv_th - 0.5f;
-    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
-    float ya = tyf - ty1, ya1 = 1.0f - ya;
-    ty1 = max(ty1, 0);
-    ty2 = min(ty2, g.tilesY - 1);
-    float txf = x * inv_tw - 0.5f;
-    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
-    float xa = txf - tx1, xa1 = 1.0f - xa;
-    tx1 = max(tx1, 0);
-    tx2 = min(tx2, g.tilesX - 1);
-    int v = c_lab_l[gray[gi]];
+    __shared__ int s_b[4];
+    const int N = h * w;
+    const size_t f = blockIdx.y;
+    if (threadIdx.x == 0) { s_b[0] = INT_MAX; s_b[1] = INT_MAX; s_b[2] = -1; s_b[3] = -1; }
+    __syncthreads();
+    int mnx = INT_MAX, mny = INT_MAX, mxx = -1, mxy = -1;
+    const float inv_tw = 1.0f / g.tw, inv_th = 1.0f / g.th;
     const uint8_t *lf = lut + f * g.tilesX * g.tilesY * 256;
-    const uint8_t *p1 = lf + (size_t)(ty1 * g.tilesX) * 256, *p2 = lf + (size_t)(ty2 * g.tilesX) * 256;
-    float a = (float)p1[tx1 * 256 + v] * xa1, b = (float)p1[tx2 * 256 + v] * xa;
-    float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
-    float res = (a + b) * ya1 + (c + d) * ya;
-    dst[gi] = (uint8_t)sat_u8((int)rintf(res));
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const int i = blockIdx.x * 4096 + k * 256 + threadIdx.x;
+        if (i >= N) break;
+        const size_t gi = f * (size_t)N + i;
+        int y = i / w, x = i - y * w;
+        float tyf = y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        float ya = tyf - ty1, ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, g.tilesY - 1);
+        float txf = x * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+        float xa = txf - tx1, xa1 = 1.0f - xa;
+        tx1 = max(tx1, 0);
+        tx2 = min(tx2, g.tilesX - 1);
+        int v = c_lab_l[gray[gi]];
+        const uint8_t *p1 = lf + (size_t)(ty1 * g.tilesX) * 256, *p2 = lf + (size_t)(ty2 * g.tilesX) * 256;
+        float a = (float)p1[tx1 * 256 + v] * xa1, b = (float)p1[tx2 * 256 + v] * xa;
+        float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
+        float res = (a + b) * ya1 + (c + d) * ya;
+        const int out = sat_u8((int)rintf(res));
+        dst[gi] = (uint8_t)out;
+        if (out > 50) { mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y); }
+    }
+    if (__ballot(mxx >= 0)) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, off, 64)); mxx = max(mxx, __shfl_xor(mxx, off, 64));
+            mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&s_b[0], mnx); atomicMin(&s_b[1], mny); atomicMax(&s_b[2], mxx); atomicMax(&s_b[3], mxy);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_b[2] >= 0) {
+        int *nr = nrect + 16 * f;   // test first: most workgroups lie inside the box already
+        if (s_b[0] < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, s_b[0]);
+        if (s_b[1] < __hip_atomic_load(nr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 1, s_b[1]);
+        if (s_b[2] > __hip_atomic_load(nr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 2, s_b[2]);
+        if (s_b[3] > __hip_atomic_load(nr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 3, s_b[3]);
+    }
 }
 
 // ---- blobs per threshold ----------------------------------------------------------------------------
@@ -921,8 +950,8 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
 // roots of components away from the rectangle border.  BRIGHT: flatten, list the ones that are roots, zero their
 // enclosed total.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, FrameState *__restrict__ st, const int *__restrict__ bk,
-                                                int *__restrict__ P, int *__restrict__ acc,
+__global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int init_bucket, FrameState *__restrict__ st,
+                                                const int *__restrict__ bk, int *__restrict__ P, int *__restrict__ acc,
                                                 const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
                                                 int *__restrict__ sw, int cnt_base, int slot)
 {
@@ -932,6 +961,13 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, FrameS
     const int nb = S[SW_BS + bucket];
     const int *list = bk + f * N + S[SW_BO + bucket];
     int *Pf = P + f * N;
+    if (init_bucket >= 1 && init_bucket < NBK) {
+        // the pixels that join at the next step become singletons now (nothing reads their entry before that)
+        const int ni = S[SW_BS + init_bucket];
+        const int *li = bk + f * N + S[SW_BO + init_bucket];
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < ni; e += SW_GRID * 256) { const int p = li[e]; Pf[p] = p; }
+    }
+    if (bucket < 1) return;
     for (int e0 = blockIdx.x * 256; e0 < nb; e0 += SW_GRID * 256) {
         const int e = e0 + threadIdx.x;
         const bool isnew = e < nb;
@@ -1223,10 +1259,11 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
     }
 }
 
-__global__ void k_region_reset(FrameState *st, int n, unsigned long long *best)
+__global__ void k_region_reset(FrameState *st, int n, unsigned long long *best, int *nrect)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
+    nrect[16 * f] = INT_MAX; nrect[16 * f + 1] = INT_MAX; nrect[16 * f + 2] = -1; nrect[16 * f + 3] = -1;
     st[f].n_groups = 0; st[f].n_kp = 0;
     best[f] = 0;
 }
@@ -1248,12 +1285,12 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if (clip > 0.0) { g.clipLimit = (int)(clip * tileTotal / 256); if (g.clipLimit < 1) g.clipLimit = 1; }
     g.lutScale = (float)255 / tileTotal;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best);
+    CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best, B.nrect);
     (void)hipMemsetAsync(B.hist, 0, (size_t)n * 16 * 256 * sizeof(unsigned int), s);
     const int strips = 8;
     CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist);
     CPE_KLAUNCH(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
-    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gray, total, h, w, g, B.lut, B.cl);
+    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + 4095) / 4096), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
     if (side) {   // the 17 one-bit planes only need the CLAHE image
@@ -1263,7 +1300,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     }
     // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
     // every brighter set and every hole of every binarisation lies inside it
-    if ((rc = ccl_set_rect_to_bbox(B.cl, n, h, w, 50, 0, B.nrect, st, s)) != CPE_OK) return rc;
+    if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
     const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(MAXSWL / 64, n, NTHR), gbk(SW_GRID, n);
@@ -1292,7 +1329,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const int *)B.sw, (const int *)B.bk, B.lab);
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, s, h, w, k, st, (const int *)B.bk, B.lab, B.cnt,
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, s, h, w, k, 0, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k);
             CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.hl + (size_t)(k - 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
@@ -1316,13 +1353,15 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         if (side) (void)hipEventRecord(side->medians, ts);
     }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
-    CPE_KLAUNCH(k_sw_self, gpx, dim3(256), 0, s, (const FrameState *)st, h, w, B.lab2);
+    // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
+    CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
+                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0);
     for (int j = 0; j < NTHR; j++) {
         const int k = NTHR - 1 - j, thr = 50 + 10 * k;
         const int hi = j == 0 ? 255 : thr + 10;
         CPE_KLAUNCH(k_sw_unite<false>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, k + 1, (const FrameState *)st,
                     (const int *)B.sw, (const int *)B.bk, B.lab2);
-        CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, st, (const int *)B.bk, B.lab2, B.cnt2,
+        CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
                     (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, k);
         if (j > 0)
             CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
