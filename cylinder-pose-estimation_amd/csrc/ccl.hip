@@ -232,43 +232,6 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
     }
 }
 
-// bounding box of the set {(img > thr) != invert} of every frame -> nrect (block-level reduction in LDS,
-// test-before-atomic: a few hundred atomics per frame instead of one per wavefront)
-__global__ __launch_bounds__(256) void k_set_bbox(const uint8_t *__restrict__ img, int h, int w, int thr, int invert,
-                                                  int *__restrict__ nrect)
-{
-    __shared__ int s_b[4];
-    const size_t N = (size_t)h * w;
-    const size_t f = blockIdx.y;
-    const uint8_t *im = img + f * N;
-    if (threadIdx.x == 0) { s_b[0] = INT_MAX; s_b[1] = INT_MAX; s_b[2] = -1; s_b[3] = -1; }
-    __syncthreads();
-    int mnx = INT_MAX, mny = INT_MAX, mxx = -1, mxy = -1;
-    const size_t i0 = (size_t)blockIdx.x * 4096;
-    for (int k = 0; k < 16; k++) {
-        size_t i = i0 + (size_t)k * 256 + threadIdx.x;
-        if (i < N && pred(im, i, thr, invert)) {
-            int y = (int)(i / w), x = (int)(i - (size_t)y * w);
-            mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y);
-        }
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, off, 64)); mxx = max(mxx, __shfl_xor(mxx, off, 64));
-        mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0 && mxx >= 0) {
-        atomicMin(&s_b[0], mnx); atomicMin(&s_b[1], mny); atomicMax(&s_b[2], mxx); atomicMax(&s_b[3], mxy);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_b[2] >= 0) {
-        int *nr = nrect + 16 * f;
-        if (s_b[0] < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, s_b[0]);
-        if (s_b[1] < __hip_atomic_load(nr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 1, s_b[1]);
-        if (s_b[2] > __hip_atomic_load(nr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 2, s_b[2]);
-        if (s_b[3] > __hip_atomic_load(nr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nr + 3, s_b[3]);
-    }
-}
-
 __global__ void k_ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, int cnt_sel)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,18 +329,6 @@ int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, op, 0);
     CPE_CHECK_LAUNCH("k_ccl_ctl");
-    return CPE_OK;
-}
-
-// working rectangle of every frame := bounding box of {(img > thr) != invert}
-int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int invert, int *nrect, FrameState *st, hipStream_t s)
-{
-    const size_t N = (size_t)h * w;
-    CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, 1, 0);
-    CPE_KLAUNCH(k_set_bbox, dim3((unsigned)((N + 4095) / 4096), n), dim3(256), 0, s, img, h, w, thr, invert, nrect);
-    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, nrect, n, h, w, 2, 0);
-    CPE_CHECK_LAUNCH("ccl_set_rect_to_bbox");
     return CPE_OK;
 }
 

@@ -18,7 +18,6 @@ namespace cpe {
 int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int conn8, int *L, int *roots, bool holes_only,
             uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0, int cnt_sel = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
-int ccl_set_rect_to_bbox(const uint8_t *img, int n, int h, int w, int thr, int invert, int *nrect, FrameState *st, hipStream_t s);
 
 namespace {
 
@@ -795,17 +794,6 @@ struct SwRect { int x0, y0, x1, y1; };
 __device__ __forceinline__ SwRect sw_rect(const FrameState *st, size_t f)
 {
     return SwRect{st[f].crect[0], st[f].crect[1], st[f].crect[2], st[f].crect[3]};
-}
-
-__global__ __launch_bounds__(256) void k_sw_self(const FrameState *__restrict__ st, int h, int w, int *__restrict__ P)
-{
-    const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if ((size_t)i >= N) return;
-    const int y = i / w, x = i - y * w;
-    const SwRect r = sw_rect(st, f);
-    if (y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) return;
-    P[f * N + i] = i;
 }
 
 // ---- pixels of the rectangle sorted by the step at which they join: bucket b is new for the dark set at threshold

@@ -185,15 +185,6 @@ def gen_pca():
         json.dump(dict(meta=META, cases=cases), f)
 
 
-if __name__ == '__main__':
-    gen_ridges()
-    gen_intersections()
-    gen_topology()
-    gen_json()
-    gen_pca()
-    print('golden vectors written to', os.path.abspath(OUT))
-
-
 def gen_subpixel():
     """modify_grayscale_Cline (util_cylinder.py:907-971; dead in the live path, call commented at :2040) on a 2-D
     grey image with draw_points=False -- cv2-free, so the REAL function runs: rows y=f(x) are re-fitted after a
@@ -242,5 +233,10 @@ def gen_subpixel():
 
 
 if __name__ == '__main__':
+    gen_ridges()
+    gen_intersections()
+    gen_topology()
+    gen_json()
+    gen_pca()
     gen_subpixel()
-    print('subpixel golden written')
+    print('golden vectors written to', os.path.abspath(OUT))
