@@ -84,9 +84,22 @@ ORC_API void orc_blur7(const uint8_t *src, int h, int w, uint8_t *dst)
 
 /* ------------------------------------------------------------------ a-5 mask_roi_around_center */
 /* returns 0 ok, 2 = no saturated spot (UnboundLocalError in the reference).  r0 = circle_radius0 */
+void orc_circle_fill(uint8_t *img, int h, int w, int cx, int cy, int radius, uint8_t c);
+int orc_mask_roi_around_center_ex(const uint8_t *hmask, const uint8_t *vmask, const uint8_t *mask_contour,
+                                  const uint8_t *gray, int h, int w, uint8_t *roi_h, uint8_t *roi_v, int *r0,
+                                  int *spot /* optional: cx, cy, a, b */, int planar);
 ORC_API int orc_mask_roi_around_center(const uint8_t *hmask, const uint8_t *vmask, const uint8_t *mask_contour,
                                        const uint8_t *gray, int h, int w, uint8_t *roi_h, uint8_t *roi_v, int *r0,
                                        int *spot /* optional: cx, cy, a, b */)
+{
+    return orc_mask_roi_around_center_ex(hmask, vmask, mask_contour, gray, h, w, roi_h, roi_v, r0, spot, 0);
+}
+
+/* planar != 0: util_plane.py:2733-2792 -- the spot is erased with a filled cv2.circle of radius int(r) (no ellipse, no
+ * radius offsets) and that radius is what the function returns */
+ORC_API int orc_mask_roi_around_center_ex(const uint8_t *hmask, const uint8_t *vmask, const uint8_t *mask_contour,
+                                          const uint8_t *gray, int h, int w, uint8_t *roi_h, uint8_t *roi_v, int *r0,
+                                          int *spot /* optional: cx, cy, a, b */, int planar)
 {
     size_t N = (size_t)h * w;
     uint8_t *bl = (uint8_t *)malloc(N), *bin = (uint8_t *)malloc(N), *cm = (uint8_t *)malloc(N);
@@ -110,7 +123,8 @@ ORC_API int orc_mask_roi_around_center(const uint8_t *hmask, const uint8_t *vmas
         int cr = rad < 30 ? cr0 + 20 : cr0 + 5;
         int minor = cr + 20 > 1 ? cr + 20 : 1;
         int a = (int)lrint((cr + 40) / 2.0), b = (int)lrint(minor / 2.0); /* python round(): half to even */
-        orc_ellipse_fill(cm, h, w, icx, icy, a, b, 0);
+        if (planar) { a = b = cr0; orc_circle_fill(cm, h, w, icx, icy, cr0, 0); }
+        else orc_ellipse_fill(cm, h, w, icx, icy, a, b, 0);
         *r0 = cr0;
         if (spot) { spot[0] = icx; spot[1] = icy; spot[2] = a; spot[3] = b; }
         st = 0;
@@ -258,10 +272,19 @@ static int flt_cmp(const void *a, const void *b)
 }
 
 /* expands_line_roi(mask, 1, mask_contour, patch 15, kernel_size) (util_cylinder.py:214-237, :137-212) */
+void orc_expand_line_roi_ex(const uint8_t *mask_roi, const uint8_t *mask_contour, int h, int w, int kernel_size, int minp,
+                            int maxp, uint8_t *out, int *dbg);
 ORC_API void orc_expand_line_roi(const uint8_t *mask_roi, const uint8_t *mask_contour, int h, int w, int kernel_size,
                                  uint8_t *out, int *dbg /* optional: [n_contours, n_valid] */)
 {
-    const int patch = 15, half = patch / 2, minp = 5, maxp = 200;
+    orc_expand_line_roi_ex(mask_roi, mask_contour, h, w, kernel_size, 5, 200, out, dbg);
+}
+
+/* minp / maxp: vertex-count window of the fragments (5..200 in util_cylinder.py:137, 8..700 in util_plane.py:140) */
+ORC_API void orc_expand_line_roi_ex(const uint8_t *mask_roi, const uint8_t *mask_contour, int h, int w, int kernel_size,
+                                    int minp, int maxp, uint8_t *out, int *dbg /* optional: [n_contours, n_valid] */)
+{
+    const int patch = 15, half = patch / 2;
     size_t N = (size_t)h * w;
     uint8_t *base = (uint8_t *)malloc(N), *exp = (uint8_t *)malloc(N);
     orc_close_rect(mask_roi, h, w, 3, 3, base);
@@ -303,6 +326,7 @@ ORC_API void orc_expand_line_roi(const uint8_t *mask_roi, const uint8_t *mask_co
         qsort(alist, nv, sizeof(float), flt_cmp);
         float gang = (nv & 1) ? alist[nv / 2] : (float)(((double)alist[nv / 2 - 1] + (double)alist[nv / 2]) / 2.0);
         uint8_t *ker = (uint8_t *)malloc((size_t)kernel_size * kernel_size);
+        int *koff = (int *)malloc((size_t)kernel_size * kernel_size * 2 * sizeof(int));
         uint8_t *dil = (uint8_t *)calloc(N, 1);
         int a = kernel_size / 2;
         for (int i = 0; i < nc; i++) {
@@ -310,6 +334,9 @@ ORC_API void orc_expand_line_roi(const uint8_t *mask_roi, const uint8_t *mask_co
             if ((double)len[i] > 0.8 * (double)glen) continue;
             float ak = fabsf(ang[i] - gang) > 5.0f ? gang : ang[i];
             orc_rotated_line_kernel(kernel_size, (double)ak, ker);
+            int nko = 0;   /* the kernel is a thin line: walk its non-zero taps only */
+            for (int kk = 0; kk < kernel_size * kernel_size; kk++)
+                if (ker[kk]) { koff[2 * nko] = kk / kernel_size; koff[2 * nko + 1] = kk % kernel_size; nko++; }
             for (int e = 0; e < 2; e++) {
                 int cx = (int)lrint((double)ep[4 * i + 2 * e]), cy = (int)lrint((double)ep[4 * i + 2 * e + 1]);
                 int x1 = cx - half > 0 ? cx - half : 0, x2 = cx + half + 1 < w ? cx + half + 1 : w;
@@ -324,12 +351,10 @@ ORC_API void orc_expand_line_roi(const uint8_t *mask_roi, const uint8_t *mask_co
                 for (int y = y1; y < y2; y++)
                     for (int x = x1; x < x2; x++) {
                         if (!base[(size_t)y * w + x]) continue;
-                        for (int ky = 0; ky < kernel_size; ky++)
-                            for (int kx = 0; kx < kernel_size; kx++) {
-                                if (!ker[ky * kernel_size + kx]) continue;
-                                int yy = y - (ky - a), xx = x - (kx - a);
-                                if (yy >= 0 && yy < h && xx >= 0 && xx < w) dil[(size_t)yy * w + xx] = 255;
-                            }
+                        for (int q = 0; q < nko; q++) {
+                            int yy = y - (koff[2 * q] - a), xx = x - (koff[2 * q + 1] - a);
+                            if (yy >= 0 && yy < h && xx >= 0 && xx < w) dil[(size_t)yy * w + xx] = 255;
+                        }
                     }
                 for (int y = by1; y < by2; y++)
                     for (int x = bx1; x < bx2; x++) {
@@ -344,7 +369,7 @@ ORC_API void orc_expand_line_roi(const uint8_t *mask_roi, const uint8_t *mask_co
                     }
             }
         }
-        free(ker); free(dil);
+        free(ker); free(koff); free(dil);
     }
     for (size_t i = 0; i < N; i++) out[i] = (exp[i] | base[i]) & mask_contour[i];
     orc_contours_free(cs);

@@ -266,3 +266,51 @@ def subpixel_refine(gray, rows, cols, window=7, step=1.0):
     """modify_grayscale_Cline(gray2d, rows, cols, draw_points=False, degree=2, step, window): status 0 or 7 (raises)"""
     gray = _u8(gray); h, w = gray.shape
     return lib().orc_subpixel_refine(_p(gray, C.c_uint8), h, w, C.byref(rows), C.byref(cols), window, C.c_double(step))
+
+
+# ---------------------------------------------------------------- row f-2: planar-target variant (orc_plane.c)
+def fit_lines_plane(rows, cols):
+    lib().orc_fit_lines_plane(C.byref(rows), C.byref(cols)); return rows, cols
+
+
+def intersections_plane(rows, cols, rect):
+    r = (C.c_int * 4)(*rect)
+    lib().orc_intersections_plane(C.byref(rows), C.byref(cols), r); return rows, cols
+
+
+def clean_plane(rows, cols):
+    lib().orc_clean_plane(C.byref(rows)); lib().orc_clean_plane(C.byref(cols)); return rows, cols
+
+
+def get_convex_hull(gray, thr=127, expansion=5):
+    gray = _u8(gray); h, w = gray.shape
+    mask = np.zeros((h, w), np.uint8); rect = (C.c_int * 4)()
+    st = lib().orc_get_convex_hull(_p(gray, C.c_uint8), h, w, thr, expansion, _p(mask, C.c_uint8), rect)
+    return st, mask, tuple(rect)
+
+
+def ellipse_se(ks):
+    se = np.zeros((ks, ks), np.uint8)
+    lib().orc_ellipse_se(ks, _p(se, C.c_uint8)); return se
+
+
+def detect_grid_plane(gray, cap=4096, debug=False):
+    """detect_grid of python_grid_detection_plane.py restated: -> dict(status, center, xy (n,2), id (n,2) = (row, col) ...)"""
+    gray = _u8(gray); h, w = gray.shape
+    center = np.zeros(2); xy = np.zeros((cap, 2)); ids = np.zeros((cap, 2), np.int32); n = C.c_int(0)
+    dbg = DetectDebug(); imgs = {}
+    if debug:
+        for k in ('binary', 'hmask', 'vmask', 'mask_contour', 'roi_h', 'roi_v', 'exp_h', 'exp_v'):
+            imgs[k] = np.zeros((h, w), np.uint8)
+            setattr(dbg, k, imgs[k].ctypes.data)
+        imgs['joints'] = np.zeros((1 << 16, 2), np.int32)
+        dbg.joints = imgs['joints'].ctypes.data; dbg.cap_joints = 1 << 16
+    st = lib().orc_detect_grid_plane(_p(gray, C.c_uint8), h, w, _p(center, C.c_double), _p(xy, C.c_double), _p(ids, C.c_int), cap,
+                                     C.byref(n), C.byref(dbg))
+    out = dict(status=st, center=center, xy=xy[:n.value].copy(), id=ids[:n.value].copy(), rect=tuple(dbg.rect),
+               r0=dbg.r0, spot=tuple(dbg.spot), n_joints=dbg.n_joints, n_cyl_joints=dbg.n_cyl_joints,
+               n_rows=dbg.n_rows, n_cols=dbg.n_cols, n_keypoints=0)
+    if debug:
+        imgs['joints'] = imgs['joints'][:dbg.n_joints].copy()
+        out.update(imgs)
+    return out

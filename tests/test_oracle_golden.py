@@ -114,3 +114,40 @@ def test_subpixel_refinement_vs_reference(orc):
     assert spec['bad_row_raises']
     bad = S.lineset_from_equations([spec['bad_row']]); none = S.lineset_from_equations([])
     assert S.subpixel_refine(gray, bad, none, spec['window'], spec['step']) == 7
+
+
+def test_plane_lines_vs_reference(orc):
+    """row f-2: the planar script's line logic against the real util_plane functions (tests/golden/plane_lines.json):
+    degree-1 fits with the merging of short columns, intersections, clean_and_relabel without sorting"""
+    from oracle import stages as S
+    d = json.load(open(os.path.join(GOLDEN, 'plane_lines.json')))
+    n_merged = 0
+    for case in d['cases']:
+        H, W = case['H'], case['W']
+        rows = S.group_points(case['centroids'], _labels_from(case, 'lab_h', H, W), case['x_off'], case['y_off'])
+        cols = S.group_points(case['centroids'], _labels_from(case, 'lab_v', H, W), case['x_off'], case['y_off'])
+        n_before = cols.nlines
+        S.fit_lines_plane(rows, cols)
+        want_c, want_r = case['fitted']['cols'], case['fitted']['rows']
+        assert cols.nlines == len(want_c) and rows.nlines == len(want_r), (case['seed'], cols.nlines, len(want_c))
+        n_merged += n_before - cols.nlines
+        for g in range(cols.nlines):
+            np.testing.assert_allclose(cols.equations()[g][:5], want_c[f'col{g + 1}'], rtol=1e-9, atol=1e-8)
+            got = [(a, b) for a, b in cols.points()[g]]
+            assert got == [tuple(p) for p in case['fitted']['col_points'][f'col{g + 1}']]
+        for g in range(rows.nlines):
+            np.testing.assert_allclose(rows.equations()[g][:5], want_r[f'row{g + 1}'], rtol=1e-9, atol=1e-8)
+        S.intersections_plane(rows, cols, (0, 0, W, H))
+        for ls, want, pre in ((rows, case['inter']['rows'], 'row'), (cols, case['inter']['cols'], 'col')):
+            for g in range(ls.nlines):
+                w_pts = want[f'{pre}{g + 1}']
+                g_pts = ls.points()[g]
+                assert len(g_pts) == len(w_pts), (case['seed'], pre, g)
+                if w_pts:
+                    assert np.abs(np.array(g_pts) - np.array(w_pts)).max() < 1e-6
+        S.clean_plane(rows, cols)
+        for ls, want, pre in ((rows, case['clean']['rows'], 'row'), (cols, case['clean']['cols'], 'col')):
+            assert ls.nlines == len(want)
+            for g in range(ls.nlines):
+                assert np.abs(np.array(ls.points()[g]) - np.array(want[f'{pre}{g + 1}'])).max() < 1e-6
+    assert n_merged >= 6      # the merge path was exercised

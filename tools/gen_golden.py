@@ -232,6 +232,62 @@ def gen_subpixel():
     np.savez_compressed(os.path.join(OUT, 'subpixel.npz'), gray=gray, spec=json.dumps(out))
 
 
+def gen_plane_lines():
+    """row f-2, the cv2-free line logic of the PLANAR script (utils/util_plane.py): group_points_by_label ->
+    create_dummy_rows_cols(1) -> fit_and_draw_polynomial(degree=1, merges runs of short columns, :411-634) ->
+    find_and_assign_intersections_P(degree=1) -> clean_and_relabel (:1204-1253: no sorting)"""
+    import utils.util_plane as up
+    cases = []
+    #      seed rows cols  split columns {col: row where the label changes}   joints removed   lonely labels
+    specs = [(11, 8, 9, {}, 0, 0), (12, 9, 8, {2: 4, 3: 5}, 3, 0), (13, 10, 10, {0: 3, 1: 3, 2: 6, 7: 5, 8: 5, 9: 2}, 6, 2),
+             (14, 6, 7, {4: 2}, 0, 1), (15, 12, 6, {1: 6, 2: 6, 3: 6}, 9, 0)]
+    for seed, nr, nc, splits, drop, lonely in specs:
+        rng = np.random.default_rng(300 + seed)
+        pts = make_joint_grid(seed, nr, nc)
+        keep = np.ones(len(pts), bool)
+        if drop:
+            keep[rng.choice(len(pts), size=drop, replace=False)] = False
+        pts = [p for p, k in zip(pts, keep) if k]
+        pts = [pts[i] for i in rng.permutation(len(pts))]
+        H, W = 480, 640
+        x_off, y_off = 20, 10
+        lab_h = np.zeros((H - y_off, W - x_off), np.int32)
+        lab_v = np.zeros((H - y_off, W - x_off), np.int32)
+        perm_r = rng.permutation(nr) + 1
+        perm_c = rng.permutation(2 * nc + lonely) + 1      # a split column gets two label values
+        centroids = []
+        for (x, y, r, c) in pts:
+            lab_h[y - y_off, x - x_off] = perm_r[r]
+            lv = perm_c[c] if (c not in splits or r < splits[c]) else perm_c[nc + c]
+            lab_v[y - y_off, x - x_off] = lv
+            centroids.append((x, y))
+        for q in range(lonely):                              # a label with a single joint: its column keeps the dummy equation
+            x, y = 40 + 7 * q, 300 + 5 * q
+            lab_v[y - y_off, x - x_off] = perm_c[2 * nc + q]
+            lab_h[y - y_off, x - x_off] = 0
+            centroids.append((x, y))
+        rows = up.group_points_by_label(centroids, lab_h, x_off, y_off)
+        cols = up.group_points_by_label(centroids, lab_v, x_off, y_off)
+        rows_d, cols_d = up.create_dummy_rows_cols(rows, cols, degree=1)
+        img = np.zeros((H, W, 3), np.uint8)
+        _, rows_d, cols_d = up.fit_and_draw_polynomial(img, rows_d, cols_d, W, H, None, degree=1)
+        fitted = dict(rows={k: [float(v) for v in e] for k, e in rows_d['equations'].items()},
+                      cols={k: [float(v) for v in e] for k, e in cols_d['equations'].items()},
+                      col_points={k: [[float(a), float(b)] for a, b in v] for k, v in cols_d['points'].items()})
+        _, ru, cu = up.find_and_assign_intersections_P(img, rows_d, cols_d, None, draw_points=False, degree=1)
+        inter = dict(rows={k: [[float(a), float(b)] for a, b in v] for k, v in ru['points'].items()},
+                     cols={k: [[float(a), float(b)] for a, b in v] for k, v in cu['points'].items()})
+        ru, cu = up.clean_and_relabel(ru, cu)
+        clean = dict(rows={k: [[float(a), float(b)] for a, b in v] for k, v in ru['points'].items()},
+                     cols={k: [[float(a), float(b)] for a, b in v] for k, v in cu['points'].items()})
+        cases.append(dict(seed=seed, H=H, W=W, x_off=x_off, y_off=y_off, centroids=[list(map(int, p)) for p in centroids],
+                          lab_h=[[int(x - x_off), int(y - y_off), int(lab_h[y - y_off, x - x_off])] for (x, y) in centroids],
+                          lab_v=[[int(x - x_off), int(y - y_off), int(lab_v[y - y_off, x - x_off])] for (x, y) in centroids],
+                          fitted=fitted, inter=inter, clean=clean))
+    with open(os.path.join(OUT, 'plane_lines.json'), 'w') as f:
+        json.dump(dict(meta=META, cases=cases), f)
+
+
 if __name__ == '__main__':
     gen_ridges()
     gen_intersections()
@@ -239,4 +295,5 @@ if __name__ == '__main__':
     gen_json()
     gen_pca()
     gen_subpixel()
+    gen_plane_lines()
     print('golden vectors written to', os.path.abspath(OUT))
