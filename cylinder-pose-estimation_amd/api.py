@@ -16,6 +16,7 @@ from .fit import GridTables, MAXP
 
 PLANES = dict(binary=0, hmask=1, vmask=2, mask_contour=3, roi_h=4, roi_v=5, exp_h=6, exp_v=7, joints=8, state=9,
               clahe=10, blur19=11, blur7=12, labels=13, sweep=14)
+TARGETS = dict(cylinder=0, plane=1)
 STATUS_TEXT = {0: 'ok', 1: 'no region (cv2.convexHull(None))', 2: 'no saturated spot (circle_radius0 unbound)',
                3: 'no valid rows/cols', 4: 'empty point list', 5: 'too few points', 6: 'workspace capacity exceeded',
                7: 'sub-pixel refinement raised (line sample above / left of the image)'}
@@ -65,9 +66,10 @@ class DetectWorkspace:
         return out
 
 
-def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpixel_step=1.0):
+def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpixel_step=1.0, target='cylinder'):
     """frames: u8 tensor [n,h,w] on the GPU -> dict(xy f64[n,MAXP,2], id i32[n,MAXP,2], n i32[n], center f64[n,2],
-    status i32[n], ws)"""
+    status i32[n], ws).  target='plane': the planar-target script (python_grid_detection_plane.py, row f-2); ids are
+    (row, col) there."""
     if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3):
         raise TypeError('frames must be a CUDA uint8 tensor [n,h,w]')
     frames = frames.contiguous()
@@ -81,7 +83,7 @@ def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpix
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     center = torch.zeros((n, 2), dtype=torch.float64, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
-    prm = _lib.CpeDetectParams(1 if subpixel else 0, subpixel_window, subpixel_step)
+    prm = _lib.CpeDetectParams(1 if subpixel else 0, subpixel_window, subpixel_step, TARGETS[target], 0)
     _lib.check(L.cpe_detect_grid_batch_ex(frames.data_ptr(), n, h, w, C.addressof(prm), ws.view.data_ptr(), ws.bytes,
                                           xy.data_ptr(), ids.data_ptr(), cnt.data_ptr(), center.data_ptr(),
                                           status.data_ptr(), torch.cuda.current_stream().cuda_stream),
@@ -114,11 +116,12 @@ def to_gray(input_img):
     raise ValueError(f'Unexpected input dimensions: {a.ndim}')
 
 
-def detect_grid(input_img, device='cuda:0'):
+def detect_grid(input_img, device='cuda:0', target='cylinder'):
     """detect_grid(input_img) -> (col_img, result_json, rows_updated, cols_updated)
-    (python_grid_detection_cylinder.py:68-110).  On a per-frame failure prints and returns None (:111-112)."""
+    (python_grid_detection_cylinder.py:68-110; target='plane': python_grid_detection_plane.py:74-119, whose ids are
+    (row, col)).  On a per-frame failure prints and returns None (:111-112)."""
     gray = to_gray(input_img)
-    det = detect_grid_batch(torch.from_numpy(gray).to(device)[None])
+    det = detect_grid_batch(torch.from_numpy(gray).to(device)[None], target=target)
     st = int(det['status'][0])
     if st != 0:
         print(f'Error in detect_grid: {STATUS_TEXT.get(st, st)}')
@@ -130,9 +133,9 @@ def detect_grid(input_img, device='cuda:0'):
         xi, yi = int(x), int(y)
         col_img[max(yi - 2, 0):yi + 3, max(xi - 2, 0):xi + 3] = (0, 255, 0)
     cols = {}
-    for (x, y), (c, r) in zip(xy, ids):
-        cols.setdefault(f'col{int(c) + 1}', []).append((float(x), float(y)))
     rows = {}
-    for (x, y), (c, r) in zip(xy, ids):
+    for (x, y), (i0, i1) in zip(xy, ids):
+        c, r = (i1, i0) if target == 'plane' else (i0, i1)
+        cols.setdefault(f'col{int(c) + 1}', []).append((float(x), float(y)))
         rows.setdefault(f'row{int(r)}', []).append((float(x), float(y)))
     return col_img, make_json(center, xy, ids), {'points': rows, 'equations': {}}, {'points': cols, 'equations': {}}

@@ -20,14 +20,15 @@ int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s,
                  const RegionSide *side);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
-int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
+int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s, int planar);
+int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
-                const RegionSide *side);
+                const RegionSide *side, int planar);
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
-                int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s);
+                int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s, int planar);
 
 namespace {
 
@@ -189,10 +190,13 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
                                             void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
                                             double *center, int32_t *status, void *stream)
 {
-    CpeDetectParams prm = {0, 7, 1.0};
+    CpeDetectParams prm = {0, 7, 1.0, CPE_TARGET_CYLINDER, 0};
     if (params) prm = *params;
     CPE_CHECK_ARG(prm.subpixel == 0 || (prm.subpixel_window >= 1 && prm.subpixel_window <= 13 && prm.subpixel_step > 0),
                   "cpe_detect_grid_batch_ex: bad sub-pixel parameters");
+    CPE_CHECK_ARG(prm.target == CPE_TARGET_CYLINDER || prm.target == CPE_TARGET_PLANE, "cpe_detect_grid_batch_ex: unknown target %d", prm.target);
+    CPE_CHECK_ARG(!(prm.target == CPE_TARGET_PLANE && prm.subpixel), "cpe_detect_grid_batch_ex: no sub-pixel refinement for the planar target");
+    const int planar = prm.target == CPE_TARGET_PLANE ? 1 : 0;
     CPE_CHECK_ARG(gray && xy && id && n_pts && center && status, "cpe_detect_grid_batch: null pointer");
     CPE_CHECK_ARG(n >= 0 && h >= 64 && w >= 64 && h <= 4096 && w <= 4096,
                   "cpe_detect_grid_batch: need n>=0 and 64 <= h,w <= 4096 (got %d,%d,%d)", n, h, w);
@@ -239,9 +243,10 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     hipStream_t s1 = X.ok ? X.s1 : s, s2 = X.ok ? X.s2 : s;
     if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
     if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
-    if ((rc = spot_stage(gray, n, h, w, M, st, s2)) != CPE_OK) return rc;
+    if ((rc = spot_stage(gray, n, h, w, M, st, s2, planar)) != CPE_OK) return rc;
     RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d};
-    if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
+    if (planar) { if ((rc = region_stage_plane(gray, n, h, w, R, st, s)) != CPE_OK) return rc; }
+    else if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
     if (X.ok) {
         (void)hipEventRecord(X.join1, X.s1);
         (void)hipEventRecord(X.join2, X.s2);
@@ -249,11 +254,11 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
         (void)hipStreamWaitEvent(s, X.join2, 0);
     }
     M.lab_h = PL(int, P_LAB0); M.lab_v = PL(int, P_LAB1);
-    if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
+    if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar)) != CPE_OK) return rc;
     if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
     if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                           n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
-                          std::max(h, w) + 128, s)) != CPE_OK)
+                          std::max(h, w) + 128, s, planar)) != CPE_OK)
         return rc;
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);

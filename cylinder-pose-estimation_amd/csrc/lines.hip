@@ -69,6 +69,97 @@ __device__ void polyfit2(const double *x, const double *y, int n, double *coef)
     for (int c = 0; c < 3; c++) coef[c] = z[c] / scale[c];
 }
 
+// np.polyfit(x, y, 1) (planar script, util_plane.py:411-634): column-scaled n x 2 Vandermonde + Householder QR
+__device__ void polyfit1(const double *x, const double *y, int n, double *coef)
+{
+    double A[MAXLP][2], b[MAXLP], scale[2], v[MAXLP];
+    for (int i = 0; i < n; i++) { A[i][0] = x[i]; A[i][1] = 1.0; b[i] = y[i]; }
+    for (int c = 0; c < 2; c++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += A[i][c] * A[i][c];
+        scale[c] = sqrt(s);
+        for (int i = 0; i < n; i++) A[i][c] /= scale[c];
+    }
+    for (int c = 0; c < 2; c++) {
+        double nrm = 0;
+        for (int i = c; i < n; i++) nrm += A[i][c] * A[i][c];
+        nrm = sqrt(nrm);
+        double alpha = A[c][c] > 0 ? -nrm : nrm;
+        for (int i = c; i < n; i++) v[i] = A[i][c];
+        v[c] -= alpha;
+        double vn = 0;
+        for (int i = c; i < n; i++) vn += v[i] * v[i];
+        if (vn == 0) continue;
+        for (int k = c; k < 2; k++) {
+            double dd = 0;
+            for (int i = c; i < n; i++) dd += v[i] * A[i][k];
+            dd = 2 * dd / vn;
+            for (int i = c; i < n; i++) A[i][k] -= dd * v[i];
+        }
+        double dd = 0;
+        for (int i = c; i < n; i++) dd += v[i] * b[i];
+        dd = 2 * dd / vn;
+        for (int i = c; i < n; i++) b[i] -= dd * v[i];
+    }
+    double z1 = b[1] / A[1][1];
+    double z0 = (b[0] - A[0][1] * z1) / A[0][0];
+    coef[0] = z0 / scale[0];
+    coef[1] = z1 / scale[1];
+}
+
+// sort n points of a line by coordinate kc (stable), fit the other coordinate: coef (c1, c0), range of the abscissa
+__device__ void fit_line_sorted(const double (*pts)[2], int n, int kc, double *coef, double &lo, double &hi)
+{
+    double tt[MAXLP], uu[MAXLP];
+    int ord[MAXLP];
+    for (int i = 0; i < n; i++) ord[i] = i;
+    for (int a = 1; a < n; a++) {
+        int o = ord[a];
+        int b = a - 1;
+        while (b >= 0 && pts[ord[b]][kc] > pts[o][kc]) { ord[b + 1] = ord[b]; b--; }
+        ord[b + 1] = o;
+    }
+    for (int i = 0; i < n; i++) { tt[i] = pts[ord[i]][kc]; uu[i] = pts[ord[i]][1 - kc]; }
+    polyfit1(tt, uu, n, coef);
+    lo = tt[0]; hi = tt[n - 1];
+}
+
+// poly_intersection_solver(row_eq, col_eq, degree 1): equations [c1, c0, lo, hi, ...]
+__device__ bool line_intersection(const double *a, const double *b, double &xs, double &ys)
+{
+    double x_min = a[2], x_max = a[3], y_min = b[2], y_max = b[3];
+    double x = 0.5 * (x_min + x_max);
+    double y = a[0] * x + a[1];
+    bool ok = false;
+    for (int it = 0; it < 50; it++) {
+        double f1 = y - (a[0] * x + a[1]), f2 = x - (b[0] * y + b[1]);
+        double da = a[0], db = b[0];
+        double det = da * db - 1.0;
+        if (det == 0 || !isfinite(det)) break;
+        double dx = (-f1 * (-db) - 1.0 * (-f2)) / det;
+        double dy = ((-da) * (-f2) - 1.0 * (-f1)) / det;
+        x += dx; y += dy;
+        if (!isfinite(x) || !isfinite(y)) break;
+        double nd = sqrt(dx * dx + dy * dy), nx = sqrt(x * x + y * y);
+        if (nd <= 1.49012e-8 * nx || nd == 0) { ok = true; break; }
+    }
+    if (!ok) return false;
+    {
+        double f1 = y - (a[0] * x + a[1]), f2 = x - (b[0] * y + b[1]);
+        double da = a[0], db = b[0];
+        double det = da * db - 1.0;
+        if (det != 0 && isfinite(det)) {
+            x += (-f1 * (-db) - 1.0 * (-f2)) / det;
+            y += ((-da) * (-f2) - 1.0 * (-f1)) / det;
+        }
+    }
+    if ((x_min - 1e-3 <= x && x <= x_max + 1e-3) && (y_min - 1e-3 <= y && y <= y_max + 1e-3)) {
+        xs = x; ys = y;
+        return true;
+    }
+    return false;
+}
+
 // poly_intersection_solver restated (analytic Newton from the reference's start point)
 __device__ bool poly_intersection(const double *a, const double *b, double &xs, double &ys)
 {
@@ -225,7 +316,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                                                LinesWS *__restrict__ wsall, double *__restrict__ o_xy,
                                                int *__restrict__ o_id, int *__restrict__ o_n, double *__restrict__ o_center,
                                                const uint8_t *__restrict__ gray, int subpixel, int sp_window, double sp_step,
-                                               float *__restrict__ sp_scratch, int sp_cap)
+                                               float *__restrict__ sp_scratch, int sp_cap, int planar)
 {
     const int f = blockIdx.x, t = threadIdx.x;
     FrameState &S = st[f];
@@ -298,7 +389,16 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             W.key[sd][g] = m;
             s_ord[sd][g] = g;
             for (int k = 0; k < 6; k++) W.eq[sd][g][k] = 0;
-            if (n >= 3) {
+            if (planar) {
+                // degree 1; rows get their final +-50 domain, columns a provisional +-10 one (merged below)
+                if (n >= 2) {
+                    double c[2], lo, hi;
+                    fit_line_sorted((const double (*)[2])W.gpts[sd][g], n, sd == 0 ? 0 : 1, c, lo, hi);
+                    const double mg = sd == 0 ? 50.0 : 10.0;
+                    lo -= mg; hi += mg;
+                    W.eq[sd][g][0] = c[0]; W.eq[sd][g][1] = c[1]; W.eq[sd][g][2] = lo; W.eq[sd][g][3] = hi; W.eq[sd][g][4] = fabs(lo - hi);
+                }
+            } else if (n >= 3) {
                 double tt[MAXLP], uu[MAXLP];
                 int ord[MAXLP];
                 const int kc = sd == 0 ? 0 : 1;  // rows: y = f(x) sorted by x; cols: x = f(y) sorted by y
@@ -322,12 +422,60 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     if (t == 0 || t == 64) {
         const int sd = t >> 6;
         sort_by_key(s_ord[sd], s_ng[sd], W.key[sd]);
-        // remove_label: first row, last col
         int n = s_ng[sd];
-        if (sd == 0) {
-            if (n > 0) { for (int k = 0; k + 1 < n; k++) s_ord[0][k] = s_ord[0][k + 1]; n--; }
-        } else {
-            if (n > 0) n--;
+        if (!planar) {
+            // remove_label: first row, last col
+            if (sd == 0) {
+                if (n > 0) { for (int k = 0; k + 1 < n; k++) s_ord[0][k] = s_ord[0][k + 1]; n--; }
+            } else {
+                if (n > 0) n--;
+            }
+        } else if (sd == 1) {
+            // fit_and_draw_polynomial of util_plane.py, steps 2-6: runs of consecutive "short" columns (domain <= 0.9 x
+            // the longest) are merged while their domains add up to at most the longest, refitted, and take the place
+            // of their first member; then every column gets its final +-50 domain
+            double thr = 0;
+            for (int k = 0; k < n; k++) thr = fmax(thr, fabs(W.eq[1][s_ord[1][k]][4]));
+            int m = 0;          // columns kept so far (s_ord[1][0..m))
+            int k = 0;
+            while (k < n) {
+                const int slot = s_ord[1][k];
+                const double dk = fabs(W.eq[1][slot][4]);
+                if (!(dk <= 0.9 * thr)) { s_ord[1][m++] = slot; k++; continue; }
+                // a run starts here: take members while they are short and the sum stays within thr
+                double cum = dk;
+                int cnt = W.gn[1][slot];
+                int k2 = k + 1;
+                while (k2 < n) {
+                    const int s2 = s_ord[1][k2];
+                    const double d2 = fabs(W.eq[1][s2][4]);
+                    if (!(d2 <= 0.9 * thr) || cum + d2 > thr) break;
+                    cum += d2;
+                    for (int q = 0; q < W.gn[1][s2]; q++) {
+                        if (cnt < MAXLP) { W.gpts[1][slot][cnt][0] = W.gpts[1][s2][q][0]; W.gpts[1][slot][cnt][1] = W.gpts[1][s2][q][1]; cnt++; }
+                        else s_ovf = 1;
+                    }
+                    k2++;
+                }
+                W.gn[1][slot] = cnt;
+                if (cnt >= 2) {
+                    double c[2], lo, hi;
+                    fit_line_sorted((const double (*)[2])W.gpts[1][slot], cnt, 1, c, lo, hi);
+                    W.eq[1][slot][0] = c[0]; W.eq[1][slot][1] = c[1]; W.eq[1][slot][2] = lo; W.eq[1][slot][3] = hi; W.eq[1][slot][4] = fabs(lo - hi);
+                    s_ord[1][m++] = slot;
+                }   // else: the members are deleted and nothing takes their place
+                k = k2;
+            }
+            n = m;
+            for (int q = 0; q < n; q++) {
+                const int slot = s_ord[1][q];
+                const int np = W.gn[1][slot];
+                if (np < 2) continue;
+                double lo = W.gpts[1][slot][0][1], hi = lo;
+                for (int i = 1; i < np; i++) { lo = fmin(lo, W.gpts[1][slot][i][1]); hi = fmax(hi, W.gpts[1][slot][i][1]); }
+                lo -= 50; hi += 50;
+                W.eq[1][slot][2] = lo; W.eq[1][slot][3] = hi; W.eq[1][slot][4] = fabs(lo - hi);
+            }
         }
         s_n[sd] = n;
     }
@@ -399,7 +547,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     for (int p = t; p < nr * nc; p += 256) {
         int r = p / nc, c = p - r * nc;
         double x, y;
-        bool ok = poly_intersection(W.eq[0][s_ord[0][r]], W.eq[1][s_ord[1][c]], x, y);
+        bool ok = planar ? line_intersection(W.eq[0][s_ord[0][r]], W.eq[1][s_ord[1][c]], x, y)
+                         : poly_intersection(W.eq[0][s_ord[0][r]], W.eq[1][s_ord[1][c]], x, y);
         if (ok) ok = (rect[0] <= x && x <= rect[0] + rect[2]) && (rect[1] <= y && y <= rect[1] + rect[3]);
         W.ival[r][c] = ok ? 1 : 0;
         W.ixy[r][c][0] = x;
@@ -434,7 +583,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         int n = 0;
         for (int k = 0; k < s_n[sd]; k++)
             if (W.in[sd][s_ord[sd][k]] > 0) s_ord[sd][n++] = s_ord[sd][k];
-        sort_by_key(s_ord[sd], n, W.key[sd]);
+        if (!planar) sort_by_key(s_ord[sd], n, W.key[sd]);   // util_plane.py's clean_and_relabel keeps the order
         s_n[sd] = n;
     }
     __syncthreads();
@@ -455,9 +604,13 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     int half = (int)(S.r0 / 5.0);
     if (half < 3) half = 3;
     if (half > 10) half = half + 5;
+    if (planar) half = (int)(S.r0 / 4.5);   // util_plane.py:1280: no clamps (0 => every window is empty => mean = NaN)
     const uint8_t *G = g7 + f * N;
     double bv = -1e300;
     int bq = INT_MAX;
+    __shared__ int s_first_nan;
+    if (t == 0) s_first_nan = 0;
+    __syncthreads();
     for (int q = t; q < PR; q += 256) {
         int r = 0;
         while (s_pref[r + 1] <= q) r++;
@@ -466,7 +619,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         int xs = (int)(x - half), xe = (int)(x + half), ys = (int)(y - half), ye = (int)(y + half);
         xs = max(xs, 0); xe = min(xe, w); ys = max(ys, 0); ye = min(ye, h);
         long cnt = (long)(xe > xs ? xe - xs : 0) * (ye > ys ? ye - ys : 0);
-        double m = -1.0;
+        double m = -1.0;   // stands for NaN (np.mean of an empty slice): never larger than anything
+        if (cnt <= 0 && q == 0) s_first_nan = 1;
         if (cnt > 0) {
             unsigned long sum = 0;
             for (int yy = ys; yy < ye; yy++)
@@ -486,7 +640,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     }
     double cx, cy;
     {
-        int q = s_ri[0], r = 0;
+        // max() over (mean, point) keeps the first item unless a later mean compares larger: a NaN first mean stays
+        int q = s_first_nan ? 0 : s_ri[0], r = 0;
         while (s_pref[r + 1] <= q) r++;
         const double *p = W.ipts[0][s_ord[0][r]][q - s_pref[r]];
         cx = p[0]; cy = p[1];
@@ -531,7 +686,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     // cols_dict: every col point -> id (col - centre col, nearest row - centre row); keep col >= 0
     if (t == 0) {
         int acc = 0;
-        for (int c = 0; c < NC; c++) { s_pref[c] = acc; acc += (c >= ccol) ? W.in[1][s_ord[1][c]] : 0; }
+        for (int c = 0; c < NC; c++) { s_pref[c] = acc; acc += (planar || c >= ccol) ? W.in[1][s_ord[1][c]] : 0; }   // remove_minus_labels: cylinder script only
         s_pref[NC] = acc;
         s_total = acc;
     }
@@ -558,8 +713,9 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             }
         }
         W.ent_xy[e][0] = px; W.ent_xy[e][1] = py;
-        W.ent_id[e][0] = c - ccol;
-        W.ent_id[e][1] = nrw >= 0 ? nrw - crow : 0;
+        const int ci = c - ccol, ri = nrw >= 0 ? nrw - crow : 0;
+        W.ent_id[e][0] = planar ? ri : ci;   // the planar script's ids are (row, col)
+        W.ent_id[e][1] = planar ? ci : ri;
     }
     __syncthreads();
     // make_json: stable sort by (col,row)
@@ -588,11 +744,11 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
 
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
-                int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s)
+                int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s, int planar)
 {
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_lines, dim3(n), dim3(256), 0, s, lab_h, lab_v, exp_h, exp_v, g7, h, w, joints, st, (LinesWS *)lines_ws, o_xy,
-                       o_id, o_n, o_center, gray, subpixel, sp_window, sp_step, sp_scratch, sp_cap);
+                       o_id, o_n, o_center, gray, subpixel, sp_window, sp_step, sp_scratch, sp_cap, planar);
     CPE_CHECK_LAUNCH("k_lines");
     return CPE_OK;
 }

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void k_blur_fused(const uint8_t *__restrict__ 
         int half = (int)(S.r0 / 5.0);
         if (half < 3) half = 3;
         if (half > 10) half = half + 5;
+        half = max(half, (int)(S.r0 / 4.5));   // the planar script's window (util_plane.py:1280)
         const int m = half + 1;
         if (gx0 > S.rect[0] + S.rect[2] + m || gx0 + BT_X < S.rect[0] - m || gy0 > S.rect[1] + S.rect[3] + m ||
             gy0 + BT_Y < S.rect[1] - m)
@@ -564,6 +565,29 @@ __device__ void fill_convex_poly_z(uint8_t *img, int h, int w, const long long *
     } while (++y <= (int)ymax);
 }
 
+// cv2.circle(img, (cx, cy), radius, 0, thickness=-1): the midpoint spans of OpenCV's Circle() (as in k_discs)
+__device__ void circle_fill_z(uint8_t *im, int h, int w, int cx, int cy, int radius)
+{
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        int ys[4] = {cy - dy, cy + dy, cy - dx, cy + dx};
+        int xa[4] = {cx - dx, cx - dx, cx - dy, cx - dy};
+        int xb[4] = {cx + dx, cx + dx, cx + dy, cx + dy};
+        for (int q = 0; q < 4; q++) {
+            if (ys[q] < 0 || ys[q] >= h) continue;
+            int x1 = max(xa[q], 0), x2 = min(xb[q], w - 1);
+            for (int x = x1; x <= x2; x++) im[(size_t)ys[q] * w + x] = 0;
+        }
+        dy++;
+        err += plus;
+        plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
 __device__ void ellipse_fill_z(uint8_t *img, int h, int w, int cx, int cy, int a, int b)
 {
     long long ccx = (long long)cx << XY_SHIFT, ccy = (long long)cy << XY_SHIFT;
@@ -597,7 +621,7 @@ __device__ void ellipse_fill_z(uint8_t *img, int h, int w, int cx, int cy, int a
 // one thread per frame: contour of the largest saturated blob -> circle -> ellipse erased from cm (pre-set to 255)
 __global__ __launch_bounds__(64) void k_spot_ellipse(const uint8_t *__restrict__ g19, int n, int h, int w,
                                                      const unsigned long long *__restrict__ best, FrameState *__restrict__ st,
-                                                     int *__restrict__ verts /* n*MAXV*2 */, uint8_t *__restrict__ cm)
+                                                     int *__restrict__ verts /* n*MAXV*2 */, uint8_t *__restrict__ cm, int planar)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
@@ -616,7 +640,8 @@ __global__ __launch_bounds__(64) void k_spot_ellipse(const uint8_t *__restrict__
     int cr = rad < 30 ? cr0 + 20 : cr0 + 5;
     int minor = cr + 20 > 1 ? cr + 20 : 1;
     int a = (int)rint((cr + 40) / 2.0), b = (int)rint(minor / 2.0);
-    ellipse_fill_z(cm + f * N, h, w, icx, icy, a, b);
+    if (planar) { a = cr0; b = cr0; circle_fill_z(cm + f * N, h, w, icx, icy, cr0); }   // util_plane.py:2733-2792: plain circle
+    else ellipse_fill_z(cm + f * N, h, w, icx, icy, a, b);
     S.r0 = cr0;
     S.spot[0] = icx; S.spot[1] = icy; S.spot[2] = a; S.spot[3] = b;
 }
@@ -672,19 +697,22 @@ __device__ void eig2_lapack(double a, double b, double c, double d, double *w, d
 }
 
 struct SegVisitor {
-    float *pts;  // 200 x 2
+    float *pts;  // maxv x 2
+    int maxv;
     int n = 0;
     __device__ __forceinline__ void point(int x, int y, bool vertex)
     {
         if (!vertex) return;
-        if (n < 200) { pts[2 * n] = (float)x; pts[2 * n + 1] = (float)y; }
+        if (n < maxv) { pts[2 * n] = (float)x; pts[2 * n + 1] = (float)y; }
         n++;
     }
-    // expand_line_roi skips contours with more than 200 vertices (util_cylinder.py:169): no need to finish those
-    __device__ __forceinline__ bool stop() const { return n > 200; }
+    // expand_line_roi skips contours with more than max_pixels vertices (util_cylinder.py:169): no need to finish those
+    __device__ __forceinline__ bool stop() const { return n > maxv; }
 };
 
-// one thread per fragment: CHAIN_APPROX_SIMPLE vertices (5..200) -> PCA end points, angle, length
+// one thread per fragment: CHAIN_APPROX_SIMPLE vertices (MINV..MAXVS: 5..200 for the cylinder script, 8..700 for the planar
+// one, expand_line_roi's min_pixels / max_pixels) -> PCA end points, angle, length
+template <int MINV, int MAXVS>
 __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ base_bits, int h, int w, int which,
                                                   const int *__restrict__ roots, int cnt_sel, FrameState *__restrict__ st,
                                                   SegRec *__restrict__ segs /* n*MAXSEG */)
@@ -697,11 +725,11 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int ws = bit_row_words(w);
     BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
-    float pts[400];
-    SegVisitor sv{pts};
+    float pts[2 * MAXVS];
+    SegVisitor sv{pts, MAXVS};
     if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
     const int n = sv.n;
-    if (n < 5 || n > 200) return;
+    if (n < MINV || n > MAXVS) return;
     // get_pca_endpoints
     float mx = 0, my = 0;
     for (int i = 0; i < n; i++) { mx += pts[2 * i]; my += pts[2 * i + 1]; }
@@ -770,12 +798,14 @@ __global__ __launch_bounds__(256) void k_seg_global(FrameState *__restrict__ st,
 
 // one workgroup per fragment end point: 15x15 patch of the mask dilated by the rotated line kernel
 // (reflected, as cv2.dilate does), eroded 3x3, OR-ed into exp.  Works on the (15 + ks)^2 support in LDS.
-constexpr int EXP_MAXKS = 176;
-constexpr int EXP_REG = 15 + EXP_MAXKS + 2;
+constexpr int EXP_MAXKS = 176;       // cylinder script: kernel 91 + r0
+constexpr int EXP_MAXKS_PLANE = 208;  // planar script: fixed 201
+template <int MAXKS>
 __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ base, int h, int w, int which,
                                                     FrameState *__restrict__ st, const SegRec *__restrict__ segs,
-                                                    uint8_t *__restrict__ exp)
+                                                    uint8_t *__restrict__ exp, int fixed_ks)
 {
+    constexpr int EXP_REG = 15 + MAXKS + 2;
     __shared__ uint8_t dil[EXP_REG * EXP_REG];
     __shared__ short koff[4096][2];
     __shared__ short ppix[225][2];
@@ -788,8 +818,8 @@ __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ 
     const SegRec r = segs[(size_t)f * MAXSEG + seg];
     const float glen = S.glen[which], gang = S.gang[which];
     if ((double)r.len > 0.8 * (double)glen) return;
-    const int ks = 91 + S.r0;
-    if (ks > EXP_MAXKS) { if (t == 0) set_overflow(S, OVF_KERNEL); return; }
+    const int ks = fixed_ks > 0 ? fixed_ks : 91 + S.r0;
+    if (ks > MAXKS) { if (t == 0) set_overflow(S, OVF_KERNEL); return; }
     const float ak = fabsf(r.angle - gang) > 5.0f ? gang : r.angle;
     const int a = ks / 2, half = 7;
     const size_t N = (size_t)h * w;
@@ -909,7 +939,7 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st,
 }
 
 // a-5 head: saturated spot -> circle_mask, r0 (depends on the grey frame only: own stream)
-int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s)
+int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s, int planar)
 {
     const size_t total = (size_t)h * w * n;
     int rc;
@@ -924,7 +954,7 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
     if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab_s, B.roots_s, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 2)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots_s, st, B.best_s);
     (void)hipMemsetAsync(B.cm, 255, total, s);
-    CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm);
+    CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm, planar);
     CPE_CHECK_LAUNCH("spot_stage");
     return CPE_OK;
 }
@@ -932,7 +962,7 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
 // a-2/a-4 (joint centroids inside rect), a-5 (roi masks), a-6 (expansion).  Needs st[].rect and mc, the joints
 // components and the spot.
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
-                const RegionSide *side)
+                const RegionSide *side, int planar)
 {
     const size_t total = (size_t)h * w * n;
     int rc;
@@ -962,10 +992,12 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
                     h, w, tiles_x, tiles_y, (const FrameState *)st, roi, base);
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_seg_trace, dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
         CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, q, st, which, (const SegRec *)segs);
         (void)hipMemsetAsync(tmp, 0, total, q);
-        CPE_KLAUNCH(k_seg_expand, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp);
+        if (planar) CPE_KLAUNCH(k_seg_expand<EXP_MAXKS_PLANE>, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 201);
+        else CPE_KLAUNCH(k_seg_expand<EXP_MAXKS>, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 0);
         CPE_KLAUNCH(k_or_and, dim3(grid1(total)), dim3(256), 0, q, (const uint8_t *)tmp, (const uint8_t *)base, (const uint8_t *)B.mc, total, exp);
         CPE_CHECK_LAUNCH("masks_stage expand");
         // cv2.connectedComponents of the expanded mask: unions only, k_lines resolves the joints' labels

@@ -1247,6 +1247,48 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
     }
 }
 
+// ---- row f-2 (planar target): get_convex_hull, util_plane.py:2590-2689 -----------------------------------------------
+// cv2.dilate with cv2.getStructuringElement(MORPH_ELLIPSE, (ks, ks)) on a 0/255 mask: 64x32 tile + apron in LDS; the element is
+// given as one half-width per row (dx[i] = -1: empty row), exactly the spans OpenCV builds.
+struct EllipseSE { int ks; int dx[32]; };
+__global__ __launch_bounds__(256) void k_dilate_ellipse(const uint8_t *__restrict__ src, int h, int w, int tiles_x, int tiles_y,
+                                                        EllipseSE se, uint8_t *__restrict__ dst)
+{
+    constexpr int TX = 64, TY = 32, RMAX = 15;
+    __shared__ uint8_t s_in[(TY + 2 * RMAX) * (TX + 2 * RMAX)];
+    const int r = se.ks / 2, IW = TX + 2 * r, IH = TY + 2 * r;
+    const int tiles = tiles_x * tiles_y;
+    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
+    const int gx0 = (tt % tiles_x) * TX, gy0 = (tt / tiles_x) * TY;
+    const size_t N = (size_t)h * w;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        int ry = i / IW, rx = i - ry * IW;
+        int y = gy0 - r + ry, x = gx0 - r + rx;
+        s_in[i] = (x >= 0 && x < w && y >= 0 && y < h) ? src[f * N + (size_t)y * w + x] : 0;   // outside: never a source
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TY * TX; i += 256) {
+        int ry = i / TX, rx = i - ry * TX;
+        int y = gy0 + ry, x = gx0 + rx;
+        if (y >= h || x >= w) continue;
+        bool on = false;
+        for (int k = 0; k < se.ks && !on; k++) {
+            const int dxk = se.dx[k];
+            if (dxk < 0) continue;
+            const uint8_t *row = &s_in[(ry + k) * IW + rx + r];   // source row y + (k - r) (the element is symmetric)
+            for (int j = -dxk; j <= dxk; j++)
+                if (row[j]) { on = true; break; }
+        }
+        dst[f * N + (size_t)y * w + x] = on ? 255 : 0;
+    }
+}
+
+__global__ void k_best_reset(int n, unsigned long long *best)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) best[f] = 0;
+}
+
 __global__ void k_region_reset(FrameState *st, int n, unsigned long long *best, int *nrect)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1380,6 +1422,47 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
     CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
+    return CPE_OK;
+}
+
+// Region stage of the planar script: mask_contour = filled hull of (filled hull of the largest bright blob, dilated by an
+// 11x11 ellipse), st[].rect = its bounding rectangle.  Every piece but the dilation is shared with the cylinder path.
+int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuffers &B, FrameState *st, hipStream_t s)
+{
+    const size_t N = (size_t)h * w, total = N * n;
+    int rc;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best, B.nrect);
+    (void)hipMemsetAsync(B.ext, 0, total, s);
+    (void)hipMemsetAsync(B.mc, 0, total, s);
+    EllipseSE se;
+    se.ks = 11;
+    for (int i = 0; i < 32; i++) se.dx[i] = -1;
+    {
+        const int r = se.ks / 2, c = se.ks / 2;
+        const double inv_r2 = r ? 1. / ((double)r * r) : 0;
+        for (int i = 0; i < se.ks; i++) {
+            const int dy = i - r;
+            int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));   // saturate_cast<int>(c * sqrt(...)) of getStructuringElement
+            se.dx[i] = std::min(dx, c);
+        }
+    }
+    for (int round = 0; round < 2; round++) {
+        const uint8_t *img = round == 0 ? gray : (const uint8_t *)B.touch;
+        const int thr = round == 0 ? 127 : 0;
+        uint8_t *dst = round == 0 ? B.ext : B.mc;
+        if (round == 1) CPE_KLAUNCH(k_best_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best);
+        if ((rc = ccl_run(img, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
+        if ((rc = build_bitplanes(img, n, h, w, thr, 0, 1, B.bits, s)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
+        CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, dst);
+        if (round == 0) {
+            const int tiles_x = (w + 63) / 64, tiles_y = (h + 31) / 32;
+            CPE_KLAUNCH(k_dilate_ellipse, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.ext, h, w, tiles_x,
+                        tiles_y, se, B.touch);
+        }
+        CPE_CHECK_LAUNCH("region_stage_plane");
+    }
     return CPE_OK;
 }
 

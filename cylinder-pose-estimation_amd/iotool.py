@@ -5,6 +5,7 @@
     Undistorter(camera_params, h, w, device)    the batched form: the fixed-point map is built once per camera
                                                 (cv2.undistort rebuilds it for every image), frames are one gather pass
 
+The planar entry module (python_grid_detection_plane.py) and the cylinder one call it for every image of a folder.
 The MATLAB entry point undistorts with `undistortImage(..., 'cubic')` (utils/preProcessing.m:3-4) instead; that second
 interpolation mode is not built.  No CPU fallback: the HIP library does the work."""
 import ctypes as C
@@ -67,7 +68,7 @@ class Undistorter:
 def undistort_image(image, camera_params, device='cuda:0'):
     """reference signature (iotool.py:22): numpy u8 image [h,w] or [h,w,c] -> undistorted numpy image.
     (Channels are independent in cv2.undistort; they are processed as a batch of planes.)"""
-    img = np.ascontiguousarray(image)
+    img = np.array(image, copy=True, order='C')     # (PIL / MATLAB hand over read-only buffers)
     if img.dtype != np.uint8 or img.ndim not in (2, 3):
         raise _lib.CpeError('undistort_image: u8 image [h,w] or [h,w,c] expected')
     planes = img[None] if img.ndim == 2 else np.ascontiguousarray(np.moveaxis(img, 2, 0))

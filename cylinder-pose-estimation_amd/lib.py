@@ -50,7 +50,8 @@ _SIGS = {
 
 
 class CpeDetectParams(C.Structure):
-    _fields_ = [('subpixel', C.c_int32), ('subpixel_window', C.c_int32), ('subpixel_step', C.c_double)]
+    _fields_ = [('subpixel', C.c_int32), ('subpixel_window', C.c_int32), ('subpixel_step', C.c_double),
+                ('target', C.c_int32), ('reserved', C.c_int32)]
 
 
 class CpeFitParams(C.Structure):

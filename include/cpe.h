@@ -99,7 +99,13 @@ typedef struct CpeDetectParams {
     int32_t subpixel;        /* 0 = off (reference behaviour) */
     int32_t subpixel_window; /* window_size (the commented call uses 7) */
     double subpixel_step;    /* sample_step (1.0) */
+    int32_t target;          /* CPE_TARGET_CYLINDER (python_grid_detection_cylinder.py) or CPE_TARGET_PLANE (row f-2:
+                                python_grid_detection_plane.py over utils/util_plane.py; point ids are (row, col) there,
+                                every column is kept, sub-pixel refinement is not available) */
+    int32_t reserved;
 } CpeDetectParams;
+#define CPE_TARGET_CYLINDER 0
+#define CPE_TARGET_PLANE 1
 CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
                                          void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
                                          double *center, int32_t *status, void *stream);

@@ -1,8 +1,9 @@
 """Drop-in entry module with the reference's name and entry points
-(python_grid_detection_cylinder.py:12-64 process_images_in_folder, :68-112 detect_grid), backed by the
-MI355X HIP kernels.  MATLAB keeps calling it unchanged:
+(python_grid_detection_plane.py:13-70 process_images_in_folder, :74-119 detect_grid), backed by the
+MI355X HIP kernels (row f-2: the planar-target variant over utils/util_plane.py; point ids are (row, col) here).
+The cylinder script's MATLAB call pattern, for reference:
 
-    py_func = py.importlib.import_module('python_grid_detection_cylinder');    % makePyGridPts.m:15
+    py_func = py.importlib.import_module('python_grid_detection_plane');    % makePyGridPts.m:15
     outputs = py_func.detect_grid(py.numpy.array(input_img));                  % makePyGridPts.m:29
     gridPts = jsondecode(char(outputs{2}));                                    % makePyGridPts.m:39-41
 
@@ -26,7 +27,7 @@ from cpe_amd import api as _api  # noqa: E402
 def detect_grid(input_img):
     """(col_img, result_json, rows_updated, cols_updated), or None after printing the error, as the reference."""
     try:
-        return _api.detect_grid(input_img)
+        return _api.detect_grid(input_img, target='plane')
     except (TypeError, ValueError, NotImplementedError) as e:     # the reference's blanket try/except (:111-112)
         print(f"Error in detect_grid: {e}")
         return None
@@ -45,7 +46,7 @@ def _undistort(img, params):
 
 
 def process_images_in_folder(json_path, folder_path, output_folder=None):
-    """python_grid_detection_cylinder.py:12-64: every image of the folder -> <stem>_arc<ext> + processed_images_data.json"""
+    """python_grid_detection_plane.py:12-64: every image of the folder -> <stem>_arc<ext> + processed_images_data.json"""
     from PIL import Image
     left_camera_params, right_camera_params = load_camera_data(json_path)
     if output_folder is None:
@@ -83,6 +84,6 @@ def process_images_in_folder(json_path, folder_path, output_folder=None):
 
 if __name__ == "__main__":
     if len(sys.argv) < 3:
-        print('usage: python python_grid_detection_cylinder.py <stereoParams.json> <input folder> [output folder]')
+        print('usage: python python_grid_detection_plane.py <stereoParams.json> <input folder> [output folder]')
         sys.exit(2)
     process_images_in_folder(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
