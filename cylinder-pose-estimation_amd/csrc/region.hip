@@ -1261,18 +1261,20 @@ __global__ __launch_bounds__(256) void k_dilate_ellipse(const uint8_t *__restric
     const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
     const int gx0 = (tt % tiles_x) * TX, gy0 = (tt / tiles_x) * TY;
     const size_t N = (size_t)h * w;
+    bool any_set = false;
     for (int i = threadIdx.x; i < IH * IW; i += 256) {
         int ry = i / IW, rx = i - ry * IW;
         int y = gy0 - r + ry, x = gx0 - r + rx;
         s_in[i] = (x >= 0 && x < w && y >= 0 && y < h) ? src[f * N + (size_t)y * w + x] : 0;   // outside: never a source
+        any_set |= s_in[i] != 0;
     }
-    __syncthreads();
+    const bool tile_has_source = __syncthreads_or(any_set ? 1 : 0) != 0;   // most tiles lie outside the hull: all zero
     for (int i = threadIdx.x; i < TY * TX; i += 256) {
         int ry = i / TX, rx = i - ry * TX;
         int y = gy0 + ry, x = gx0 + rx;
         if (y >= h || x >= w) continue;
         bool on = false;
-        for (int k = 0; k < se.ks && !on; k++) {
+        for (int k = 0; tile_has_source && k < se.ks && !on; k++) {
             const int dxk = se.dx[k];
             if (dxk < 0) continue;
             const uint8_t *row = &s_in[(ry + k) * IW + rx + r];   // source row y + (k - r) (the element is symmetric)
