@@ -151,3 +151,39 @@ def test_plane_lines_vs_reference(orc):
             for g in range(ls.nlines):
                 assert np.abs(np.array(ls.points()[g]) - np.array(want[f'{pre}{g + 1}'])).max() < 1e-6
     assert n_merged >= 6      # the merge path was exercised
+
+
+def _lineset_from_points(S, lines):
+    ls = S.LineSet(); ls.nlines = len(lines)
+    for g, pts in enumerate(lines):
+        ls.npts[g] = len(pts)
+        for k, (x, y) in enumerate(pts):
+            ls.pts[g][k][0] = x; ls.pts[g][k][1] = y
+    return ls
+
+
+def test_indexing_vs_reference(orc):
+    """indexing_data (+ remove_minus_labels) + make_json of both scripts against the real functions, the blurred image
+    being an input of the fixture (tests/golden/indexing.npz): centre, ids, order, coordinates"""
+    import ctypes as C
+    from oracle import stages as S
+    z = np.load(os.path.join(GOLDEN, 'indexing.npz'))
+    spec = json.loads(str(z['spec']))
+    for i, case in enumerate(spec['cases']):
+        img = z[f'img_{i}']
+        rows = _lineset_from_points(S, case['rows']); cols = _lineset_from_points(S, case['cols'])
+        if case['variant'] == 'cylinder':
+            n, center, xy, ids = S.index_points(rows, cols, img, case['r0'])
+        else:
+            h, w = img.shape
+            center = np.zeros(2); xy = np.zeros((4096, 2)); ids = np.zeros((4096, 2), np.int32)
+            n = orc.lib().orc_index_points_plane(C.byref(rows), C.byref(cols), img.ctypes.data_as(C.c_void_p), h, w, case['r0'],
+                                                 center.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p),
+                                                 ids.ctypes.data_as(C.c_void_p), 4096)
+            xy, ids = xy[:n], ids[:n]
+        js = case['json']
+        tag = (case['variant'], case['seed'])
+        assert n == len(js['points']), tag
+        assert list(center) == js['center_point'], tag
+        assert ids.tolist() == [p['id'] for p in js['points']], tag
+        assert xy.tolist() == [[p['x'], p['y']] for p in js['points']], tag

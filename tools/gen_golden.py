@@ -7,7 +7,8 @@ The reference's Python half imports `cv2`, which does not exist in this image.  
 SURVEY.md section 8c / Appendix A, an EMPTY stub module is registered for `cv2` (only the two
 drawing calls `line`/`circle` are no-ops so that drawing code paths pass); no image-processing
 function is faked, so only the cv2-free reference functions can run -- those are the ones
-exercised here.  Library versions are stored in every fixture's metadata.
+exercised here.  One exception, stated where it happens (gen_indexing): indexing_data's single
+cv2.GaussianBlur call is the identity there, the blurred image being an INPUT of that fixture.  Library versions are stored in every fixture's metadata.
 
 Outputs (small, committed): tests/golden/*.npz, tests/golden/*.json
 Nothing from /root/reference is copied: fixtures are inputs + the outputs the reference produced.
@@ -288,6 +289,66 @@ def gen_plane_lines():
         json.dump(dict(meta=META, cases=cases), f)
 
 
+def gen_indexing():
+    """indexing_data (+ remove_minus_labels) + make_json of BOTH scripts (util_cylinder.py:1350-1571, util_plane.py:1255-1472).
+    The only cv2 call inside is GaussianBlur(input_image, (7,7), 0); here the ALREADY BLURRED image is the fixture's input
+    and cv2.GaussianBlur is the identity while the real function runs (the blur itself is [ext] and checked elsewhere), so
+    what is pinned is the function's own logic: window means (incl. the plane's half = int(r/4.5), which can be 0),
+    first-maximum centre, nearest row / column, ids, ordering."""
+    import utils.util_plane as up
+    cases = []
+    imgs = {}
+    for variant, mod in (('cylinder', uc), ('plane', up)):
+        for seed, nr, nc, r0 in [(21, 7, 8, 14), (22, 9, 6, 37), (23, 5, 11, 60), (24, 6, 6, 3)]:
+            rng = np.random.default_rng(500 + seed)
+            H, W = 420, 520
+            yy0, xx0 = np.mgrid[0:H, 0:W]
+            img = (12 + (xx0 * 7 + yy0 * 13 + seed) % 17).astype(np.uint8)      # deterministic texture (compresses well)
+            rows = {"points": {}, "equations": {}}
+            cols = {"points": {}, "equations": {}}
+            grid = {}
+            for r in range(nr):
+                for c in range(nc):
+                    x = 60.0 + 48.5 * c + 1.7 * r + rng.uniform(-0.4, 0.4)
+                    y = 55.0 + 44.25 * r + 0.9 * c + rng.uniform(-0.4, 0.4)
+                    if rng.uniform() < 0.08:
+                        continue                      # a missing intersection
+                    grid[(r, c)] = (float(x), float(y))
+            for r in range(nr):
+                pts = [grid[(r, c)] for c in range(nc) if (r, c) in grid]
+                if pts:
+                    rows["points"][f"row{r + 1}"] = pts
+            for c in range(nc):
+                pts = [grid[(r, c)] for r in range(nr) if (r, c) in grid]
+                if pts:
+                    cols["points"][f"col{c + 1}"] = pts
+            # a bright patch near one grid point decides the centre
+            cr, cc = nr // 2, nc // 2 - 1
+            while (cr, cc) not in grid:
+                cc += 1
+            bx, by = grid[(cr, cc)]
+            yy, xx = np.mgrid[0:H, 0:W]
+            img = np.clip(img + 200 * np.exp(-0.5 * (((xx - bx) / 9.0) ** 2 + ((yy - by) / 9.0) ** 2)), 0, 255).astype(np.uint8)
+            saved = getattr(cv2, 'GaussianBlur', None)
+            cv2.GaussianBlur = lambda im, k, s_: im
+            try:
+                out = mod.indexing_data(rows, cols, img, None, r0)
+            finally:
+                if saved is None:
+                    del cv2.GaussianBlur
+                else:
+                    cv2.GaussianBlur = saved
+            result_json, result_dict, rows_dict, cols_dict, center_point = out
+            if variant == 'cylinder':
+                cols_dict = mod.remove_minus_labels(cols_dict)
+            js = json.loads(mod.make_json(center_point, cols_dict))
+            imgs[f'img_{len(cases)}'] = img
+            cases.append(dict(variant=variant, seed=seed, r0=r0, H=H, W=W,
+                              rows=[[list(p) for p in v] for v in rows["points"].values()],
+                              cols=[[list(p) for p in v] for v in cols["points"].values()], json=js))
+    np.savez_compressed(os.path.join(OUT, 'indexing.npz'), spec=json.dumps(dict(meta=META, cases=cases)), **imgs)
+
+
 if __name__ == '__main__':
     gen_ridges()
     gen_intersections()
@@ -296,4 +357,5 @@ if __name__ == '__main__':
     gen_pca()
     gen_subpixel()
     gen_plane_lines()
+    gen_indexing()
     print('golden vectors written to', os.path.abspath(OUT))
