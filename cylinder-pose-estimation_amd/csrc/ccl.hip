@@ -77,45 +77,50 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
     }
 }
 
-// grid = (ceil(N / 1024), n): a thread owns 4 consecutive pixels (one dword of the image when rows allow), so the
-// common case -- none of them in the set -- costs one load and no 64-bit index arithmetic
+// grid = (ceil(N / CCL_BLK_PX), n): a workgroup walks CCL_BLK_PX pixels, a thread 4 consecutive ones per step (one dword
+// of the image when rows allow), so the common case -- none of them in the set -- costs one load and no 64-bit index
+// arithmetic, and the grid stays small enough that workgroup dispatch is not what the pass waits for
+constexpr int CCL_BLK_PX = 8192;
 __global__ __launch_bounds__(256) void k_ccl_merge(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                    int invert, int conn8, const FrameState *__restrict__ st, int use_rect,
                                                    int *__restrict__ L)
 {
     const int N = h * w;
     const size_t f = blockIdx.y;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= N) return;
     const Rect r = get_rect(st, f, use_rect, h, w);
-    int y = i0 / w, x = i0 - y * w;
-    if (y > r.y1 || y + 1 < r.y0) return;
     const uint8_t *im = img + f * (size_t)N;
-    if (((((size_t)im) | (size_t)N) & 3) == 0) {
-        const uint32_t v4 = *reinterpret_cast<const uint32_t *>(im + i0);
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < 4; k++) any |= ((((int)((v4 >> (8 * k)) & 255u) > thr) ? 1 : 0) != invert);
-        if (!any) return;
-    }
     int *Lf = L + f * (size_t)N;
-    for (int k = 0; k < 4; k++, x++) {
-        const int i = i0 + k;
-        if (i >= N) break;
-        if (x == w) { x = 0; y++; }
-        if (y <= r.y0 || y > r.y1 || x < r.x0 || x > r.x1) continue;
-        if (!pred(im, i, thr, invert)) continue;
-        const bool up = pred(im, i - w, thr, invert);
-        const bool left = x > r.x0 && pred(im, i - 1, thr, invert);
-        if (up) {
-            bool upleft = x > r.x0 && pred(im, i - w - 1, thr, invert);
-            if (!(left && upleft)) uf_unite(Lf, i, i - w);
-        } else if (conn8) {
-            if (x < r.x1 && pred(im, i - w + 1, thr, invert)) {
-                bool right = pred(im, i + 1, thr, invert);
-                if (!right) uf_unite(Lf, i, i - w + 1);
+    const bool aligned = ((((size_t)im) | (size_t)N) & 3) == 0;
+    for (int it = 0; it < CCL_BLK_PX / 1024; it++) {
+        const int i0 = blockIdx.x * CCL_BLK_PX + it * 1024 + threadIdx.x * 4;
+        if (i0 >= N) break;
+        int y = i0 / w, x = i0 - y * w;
+        if (y > r.y1 || y + 1 < r.y0) continue;
+        if (aligned) {
+            const uint32_t v4 = *reinterpret_cast<const uint32_t *>(im + i0);
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) any |= ((((int)((v4 >> (8 * k)) & 255u) > thr) ? 1 : 0) != invert);
+            if (!any) continue;
+        }
+        for (int k = 0; k < 4; k++, x++) {
+            const int i = i0 + k;
+            if (i >= N) break;
+            if (x == w) { x = 0; y++; }
+            if (y <= r.y0 || y > r.y1 || x < r.x0 || x > r.x1) continue;
+            if (!pred(im, i, thr, invert)) continue;
+            const bool up = pred(im, i - w, thr, invert);
+            const bool left = x > r.x0 && pred(im, i - 1, thr, invert);
+            if (up) {
+                bool upleft = x > r.x0 && pred(im, i - w - 1, thr, invert);
+                if (!(left && upleft)) uf_unite(Lf, i, i - w);
+            } else if (conn8) {
+                if (x < r.x1 && pred(im, i - w + 1, thr, invert)) {
+                    bool right = pred(im, i + 1, thr, invert);
+                    if (!right) uf_unite(Lf, i, i - w + 1);
+                }
+                if (x > r.x0 && !left && pred(im, i - w - 1, thr, invert)) uf_unite(Lf, i, i - w - 1);
             }
-            if (x > r.x0 && !left && pred(im, i - w - 1, thr, invert)) uf_unite(Lf, i, i - w - 1);
         }
     }
 }
@@ -141,6 +146,61 @@ __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, in
     const int *Lf = L + f * N;
     int v = Lf[(size_t)y * w + x];
     if (v >= 0) touch[f * N + uf_find(Lf, v)] = 1;
+}
+
+// component list only (roots-only passes): a root is a pixel of the set whose label is its own index.  Same walk as
+// k_ccl_merge (CCL_BLK_PX pixels per workgroup, 4 per thread and step, dword reject).
+__global__ __launch_bounds__(256) void k_ccl_roots4(const uint8_t *__restrict__ img, int h, int w, int thr, int invert,
+                                                    FrameState *__restrict__ st, int use_rect, const int *__restrict__ L,
+                                                    int *__restrict__ roots, int cnt_sel)
+{
+    const int N = h * w;
+    const size_t f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const uint8_t *im = img + f * (size_t)N;
+    const int *Lf = L + f * (size_t)N;
+    const Rect r = get_rect(st, f, use_rect, h, w);
+    const bool aligned = ((((size_t)im) | (size_t)N) & 3) == 0;
+    for (int it = 0; it < CCL_BLK_PX / 1024; it++) {
+        const int i0 = blockIdx.x * CCL_BLK_PX + it * 1024 + threadIdx.x * 4;
+        bool cand[4] = {false, false, false, false};
+        if (i0 < N) {
+            int y = i0 / w, x = i0 - y * w;
+            if (!(y > r.y1 || y + 1 < r.y0)) {
+                bool any = true;
+                if (aligned) {
+                    const uint32_t v4 = *reinterpret_cast<const uint32_t *>(im + i0);
+                    any = false;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) any |= ((((int)((v4 >> (8 * k)) & 255u) > thr) ? 1 : 0) != invert);
+                }
+                if (any) {
+                    for (int k = 0; k < 4; k++, x++) {
+                        const int i = i0 + k;
+                        if (i >= N) break;
+                        if (x == w) { x = 0; y++; }
+                        if (y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) continue;
+                        cand[k] = pred(im, i, thr, invert) && Lf[i] == i;
+                    }
+                }
+            }
+        }
+        if (!__ballot(cand[0] || cand[1] || cand[2] || cand[3])) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long rb = __ballot(cand[k]);
+            if (!rb) continue;
+            int base = 0;
+            const int leader = __ffsll((long long)rb) - 1;
+            if (lane == leader) base = atomicAdd(root_counter(st[f], cnt_sel), __popcll(rb));
+            base = __shfl(base, leader, 64);
+            if (cand[k]) {
+                const int q = base + __popcll(rb & ((1ull << lane) - 1ull));
+                if (q < MAXROOTS) roots[f * MAXROOTS + q] = i0 + k;
+                else set_overflow(st[f], OVF_ROOTS);
+            }
+        }
+    }
 }
 
 // flatten + count + collect roots + bounding box, one read of the label plane.
@@ -349,7 +409,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0, cnt_sel);
     CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                 count_mode ? cnt : (int *)nullptr, sparse);
-    CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + 1023) / 1024), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
+    CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
                 (const FrameState *)st, use_rect, L);
     if (holes_only) {
         (void)hipMemsetAsync(touch, 0, total, s);
@@ -357,7 +417,10 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
         CPE_KLAUNCH(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const int *)L, n, h, w, (const FrameState *)st,
                     use_rect, touch);
     }
-    if (!(flags & 2))
+    if (flags & 1)
+        CPE_KLAUNCH(k_ccl_roots4, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L,
+                    roots, cnt_sel);
+    else if (!(flags & 2))
         CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
                     holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1, cnt_sel);
     CPE_CHECK_LAUNCH("ccl_run");
