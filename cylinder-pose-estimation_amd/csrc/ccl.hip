@@ -214,12 +214,14 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
                                                     int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect, int sparse,
                                                     int noflatten, int cnt_sel)
 {
-    // grid = (ceil(N / 256), n): a workgroup never straddles two frames, so every wave-level aggregate below is
-    // per frame
+    // grid = (ceil(N / 2048), n): a workgroup never straddles two frames, so every wave-level aggregate below is
+    // per frame; 8 steps of 256 pixels per workgroup keep the grid (and its dispatch time) small
     const size_t N = (size_t)h * w;
     const size_t f = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    for (int it = 0; it < 8; it++) {
+    const int i = blockIdx.x * 2048 + it * 256 + threadIdx.x;
+    if ((size_t)(blockIdx.x * 2048 + it * 256) >= N) break;
     const size_t gi = f * N + (size_t)i;
     int root = -1, x = 0, y = 0;
     if ((size_t)i < N) {
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             if (lane == leader) atomicAdd(&cnt[f * N + lk], __popcll(same));
             active &= ~same;
         }
+    }
     }
 }
 
@@ -421,7 +424,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
         CPE_KLAUNCH(k_ccl_roots4, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L,
                     roots, cnt_sel);
     else if (!(flags & 2))
-        CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
+        CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 2047) / 2048), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
                     holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1, cnt_sel);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;

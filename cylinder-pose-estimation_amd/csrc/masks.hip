@@ -117,10 +117,48 @@ __global__ __launch_bounds__(256) void k_and3(const uint8_t *a, const uint8_t *b
     size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gi < total) dst[gi] = (a[gi] & b[gi]) & c[gi];
 }
-__global__ __launch_bounds__(256) void k_or_and(const uint8_t *a, const uint8_t *b, const uint8_t *c, size_t total, uint8_t *dst)
+// dst = ((a | b) != 0 ? 255 : 0) & c with c = mask_contour, which is zero outside the region rectangle: rows outside it are
+// written as zeros without reading anything.  grid = (ceil(N / 16384), n), 16 bytes per thread and step when rows allow.
+__global__ __launch_bounds__(256) void k_or_and(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                const uint8_t *__restrict__ c, int h, int w, const FrameState *__restrict__ st,
+                                                uint8_t *__restrict__ dst)
 {
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi < total) dst[gi] = ((a[gi] ? 255 : 0) | (b[gi] ? 255 : 0)) & c[gi];
+    const int N = h * w;
+    const size_t f = blockIdx.y;
+    const int *r = st[f].rect;
+    const bool none = st[f].status == CPE_ST_NO_REGION;
+    const int y0 = r[1], y1 = r[1] + r[3] - 1;
+    const size_t o = f * (size_t)N;
+    const bool vec = ((((size_t)a | (size_t)b | (size_t)c | (size_t)dst) & 15) == 0) && (N % 16 == 0);
+    for (int it = 0; it < 4; it++) {
+        const int i0 = blockIdx.x * 16384 + it * 4096 + threadIdx.x * 16;
+        if (i0 >= N) break;
+        const int ya = i0 / w, yb = min(i0 + 15, N - 1) / w;
+        const bool outside = none || yb < y0 || ya > y1;
+        if (vec) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (!outside) {
+                const uint4 va = *reinterpret_cast<const uint4 *>(a + o + i0), vb = *reinterpret_cast<const uint4 *>(b + o + i0);
+                const uint4 vc = *reinterpret_cast<const uint4 *>(c + o + i0);
+                auto f4 = [](uint32_t x, uint32_t y, uint32_t z) {
+                    uint32_t r4 = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t on = (((x | y) >> (8 * k)) & 255u) ? 255u : 0u;
+                        r4 |= (on & ((z >> (8 * k)) & 255u)) << (8 * k);
+                    }
+                    return r4;
+                };
+                v = make_uint4(f4(va.x, vb.x, vc.x), f4(va.y, vb.y, vc.y), f4(va.z, vb.z, vc.z), f4(va.w, vb.w, vc.w));
+            }
+            *reinterpret_cast<uint4 *>(dst + o + i0) = v;
+        } else {
+            for (int k = 0; k < 16 && i0 + k < N; k++) {
+                const size_t gi = o + i0 + k;
+                dst[gi] = outside ? 0 : (uint8_t)(((a[gi] ? 255 : 0) | (b[gi] ? 255 : 0)) & c[gi]);
+            }
+        }
+    }
 }
 
 // a-5 tail + a-6 head in one kernel:  roi = open3x3(mask & circle_mask & mask_contour)  (util_cylinder.py:1995-2005),
@@ -998,7 +1036,8 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
         (void)hipMemsetAsync(tmp, 0, total, q);
         if (planar) CPE_KLAUNCH(k_seg_expand<EXP_MAXKS_PLANE>, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 201);
         else CPE_KLAUNCH(k_seg_expand<EXP_MAXKS>, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 0);
-        CPE_KLAUNCH(k_or_and, dim3(grid1(total)), dim3(256), 0, q, (const uint8_t *)tmp, (const uint8_t *)base, (const uint8_t *)B.mc, total, exp);
+        CPE_KLAUNCH(k_or_and, dim3((unsigned)(((size_t)h * w + 16383) / 16384), n), dim3(256), 0, q, (const uint8_t *)tmp, (const uint8_t *)base,
+                    (const uint8_t *)B.mc, h, w, (const FrameState *)st, exp);
         CPE_CHECK_LAUNCH("masks_stage expand");
         // cv2.connectedComponents of the expanded mask: unions only, k_lines resolves the joints' labels
         if ((rc = ccl_run(exp, n, h, w, 0, 0, 1, which ? B.lab_v : B.lab_h, nullptr, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 2)) != CPE_OK)
