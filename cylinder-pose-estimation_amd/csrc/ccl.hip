@@ -313,32 +313,41 @@ __global__ void k_ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int o
     // op 3: keep crect (a superset of the next, smaller set), accumulator already empty
 }
 
-// one wavefront per 64 pixels of a row: a ballot per threshold is the 64-bit group of that plane
+// one wavefront per 512 pixels of a row (8 groups of 64): a ballot per threshold is the 64-bit group of that plane; lane t
+// collects plane t's eight groups and writes them as 64 contiguous bytes
 __global__ __launch_bounds__(256) void k_bitplanes(const uint8_t *__restrict__ img, int rows_total, int h, int w, int thr0, int step,
                                                    int nplanes, uint32_t *__restrict__ planes)
 {
     const int lane = threadIdx.x & 63;
-    const int chunks = (w + 63) >> 6;
+    const int chunks = (w + 63) >> 6, groups = (chunks + 7) >> 3;
     const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= (long long)rows_total * chunks) return;
-    const int row = (int)(gw / chunks), c = (int)(gw - (long long)row * chunks);
+    if (gw >= (long long)rows_total * groups) return;
+    const int row = (int)(gw / groups), g = (int)(gw - (long long)row * groups);
     const int f = row / h, y = row - f * h;
-    const int x = c * 64 + lane;
-    const int v = x < w ? (int)img[(size_t)row * w + x] : -1;
     const int ws = bit_row_words(w);
     const size_t plane_words = (size_t)h * ws;
     uint32_t *out = planes + (size_t)f * nplanes * plane_words + (size_t)y * ws;
-    unsigned long long mine = 0;
-    for (int t = 0; t < nplanes; t++) {
-        unsigned long long b = __ballot(v > thr0 + t * step);
-        if (lane == t) mine = b;
+    unsigned long long mine[8];
+    const int c0 = g * 8, nc = min(8, chunks - c0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        mine[q] = 0;
+        if (q < nc) {
+            const int x = (c0 + q) * 64 + lane;
+            const int v = x < w ? (int)img[(size_t)row * w + x] : -1;
+            for (int t = 0; t < nplanes; t++) {
+                unsigned long long b = __ballot(v > thr0 + t * step);
+                if (lane == t) mine[q] = b;
+            }
+        }
     }
     if (lane < nplanes) {
         uint32_t *o = out + (size_t)lane * plane_words;
-        o[1 + 2 * c] = (uint32_t)mine;
-        o[2 + 2 * c] = (uint32_t)(mine >> 32);
-        if (c == 0) o[0] = 0;
-        if (c == chunks - 1) for (int k = 1 + 2 * chunks; k < ws; k++) o[k] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (q < nc) { o[1 + 2 * (c0 + q)] = (uint32_t)mine[q]; o[2 + 2 * (c0 + q)] = (uint32_t)(mine[q] >> 32); }
+        if (g == 0) o[0] = 0;
+        if (g == groups - 1) for (int k = 1 + 2 * chunks; k < ws; k++) o[k] = 0;
     }
 }
 
@@ -381,7 +390,7 @@ int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step,
         CPE_CHECK_LAUNCH("k_bitplane1");
         return CPE_OK;
     }
-    const long long waves = (long long)n * h * ((w + 63) >> 6);
+    const long long waves = (long long)n * h * ((((w + 63) >> 6) + 7) >> 3);
     CPE_KLAUNCH(k_bitplanes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, img, n * h, h, w, thr0, step, nplanes, planes);
     CPE_CHECK_LAUNCH("k_bitplanes");
     return CPE_OK;
