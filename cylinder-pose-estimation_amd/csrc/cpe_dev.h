@@ -64,6 +64,7 @@ struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
 struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
     int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
+    int *hpar; uint8_t *htime;   // merge history of the bright forest: (absorbing root, step) per absorbed entry
     uint32_t *pool;   // border points of the hole traces (chunked)
     unsigned short *blob_ch;   // first 16 chunk ids of every blob's border
     int maxch, maxdf;          // capacities per frame and threshold: border-point chunks, distance scratch (doubles)

@@ -771,18 +771,38 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     if (t == 0) S.n_groups = ng;
 }
 
-// enclosed-hole pixel totals per bright component of threshold slot k:
-//   encl[component of the pixel west of the hole's first pixel] += |hole|
-__global__ __launch_bounds__(64) void k_enclosed(const int2 *__restrict__ hl, const int *__restrict__ sw, int slot,
-                                                 const int *__restrict__ Pfg, int h, int w, int *__restrict__ encl)
+// Enclosed-hole pixel totals of the bright components of every threshold, after both sweeps:
+//   encl[component (at that threshold) of the pixel west of the hole's first pixel] += |hole|
+// The bright forest of step t is read back from its merge history: an entry that stopped being a root at step j
+// carries (hpar = the root that absorbed it, htime = j); following the links with htime <= t from any pixel of the
+// step-t bright set ends at its root of step t.  One workgroup per frame walks the 17 thresholds; the totals live in
+// the accumulator plane only between the two barriers of a threshold (atomics both ways: no stale L1 lines).
+#define ENC_NT 1024
+__global__ __launch_bounds__(ENC_NT) void k_enclosed_all(const int2 *__restrict__ hl, int2 *__restrict__ bl, const int *__restrict__ sw,
+                                                         const int *__restrict__ hpar, const uint8_t *__restrict__ htime,
+                                                         int h, int w, int *__restrict__ encl)
 {
-    const int f = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(sw[(size_t)f * SW_STRIDE + SW_NH + slot], MAXSWL)) return;
-    const size_t N = (size_t)h * w;
-    const int2 e = hl[((size_t)f * NTHR + slot) * MAXSWL + k];
-    const int c = uf_find(Pfg + f * N, e.x - 1);      // bright pixel west of the hole
-    atomicAdd(&encl[f * N + c], min(e.y, 5000));
+    const size_t N = (size_t)h * w, f = blockIdx.x;
+    const int *S = sw + f * SW_STRIDE;
+    const int *hp = hpar + f * N;
+    const uint8_t *ht = htime + f * N;
+    int *ef = encl + f * N;
+    for (int slot = 0; slot < NTHR; slot++) {
+        const int t = NTHR - 1 - slot;                     // bright step of this threshold
+        const int nh = min(S[SW_NH + slot], MAXSWL), nl = min(S[SW_NL + slot], MAXSWL);
+        for (int k = threadIdx.x; k < nh; k += ENC_NT) {
+            const int2 e = hl[(f * NTHR + slot) * MAXSWL + k];
+            int c = e.x - 1;                               // bright pixel west of the hole
+            while ((int)ht[c] <= t) c = hp[c];
+            atomicAdd(&ef[c], min(e.y, 5000));
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < nl; k += ENC_NT) {
+            int2 &g = bl[(f * NTHR + slot) * MAXSWL + k];
+            g.y = atomicExch(&ef[g.x], 0);
+        }
+        __syncthreads();
+    }
 }
 
 // ---- the 17 binarisations as two growing union-finds ------------------------------------------------------
@@ -941,7 +961,8 @@ template <bool DARK>
 __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int init_bucket, FrameState *__restrict__ st,
                                                 const int *__restrict__ bk, int *__restrict__ P, int *__restrict__ acc,
                                                 const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
-                                                int *__restrict__ sw, int cnt_base, int slot)
+                                                int *__restrict__ sw, int cnt_base, int slot,
+                                                int *__restrict__ hpar, uint8_t *__restrict__ htime)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -963,7 +984,10 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
         if (isnew) {
             i = list[e];
             root = uf_find_c(Pf, i);
-            if (root != i) Pf[i] = root;
+            if (root != i) {
+                Pf[i] = root;
+                if (!DARK) { hpar[f * N + i] = root; htime[f * N + i] = (uint8_t)epoch; }   // joined `root` at this step
+            }
         }
         bool is_root = isnew && root == i;
         if (DARK) {
@@ -989,7 +1013,8 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
                                                 const int *__restrict__ src_cnt, int src_cnt_stride,
                                                 int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
                                                 int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
-                                                int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot)
+                                                int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                                int *__restrict__ hpar, uint8_t *__restrict__ htime)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1007,6 +1032,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
         } else {
             keep = uf_load(Pf, r) == r;
             if (keep) acc[f * N + r] = 0;
+            else { hpar[f * N + r] = uf_find_c(Pf, r); htime[f * N + r] = (uint8_t)epoch; }   // absorbed at this step
         }
     }
     sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXSWL, &st[f]);
@@ -1345,68 +1371,68 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     }
     const int per = 2 * w + 2 * h;
     const size_t lstride = (size_t)NTHR * MAXSWL * 2;   // ints per frame of a list array
+    // the dark sweep and the hole borders run on the helper stream (if any) beside the bright sweep: the two forests
+    // only meet in k_enclosed_all
+    hipStream_t ds = side ? side->s : s;
+    if (side) { (void)hipEventRecord(side->dark_done, s); (void)hipStreamWaitEvent(ds, side->dark_done, 0); }
     // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count)
     for (int k = 0; k < NTHR; k++) {
         const int thr = 50 + 10 * k, epoch = k + 1;
         if (k == 0) {
             // the bulk of the dark set: run-based labelling, flattened; pixels outside it start as singletons
-            if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, s, 2)) != CPE_OK) return rc;
-            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
+            if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 2)) != CPE_OK) return rc;
+            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_old<true>, dim3(MAXROOTS / 256, n), dim3(256), 0, s, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
+            CPE_KLAUNCH(k_sw_old<true>, dim3(MAXROOTS / 256, n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
                         (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
-                        B.hl, B.sw, (int)SW_NH, k);
+                        B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
         } else {
-            CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
+            CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, ds, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
                         (const int *)B.sw, (const int *)B.bk, B.lab);
-            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const uint8_t *)B.cl, n, h, w, thr,
+            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, s, h, w, k, 0, st, (const int *)B.bk, B.lab, B.cnt,
-                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, s, (const int *)B.hl + (size_t)(k - 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, 0, st, (const int *)B.bk, B.lab, B.cnt,
+                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)B.hl + (size_t)(k - 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
-                        B.hl, B.sw, (int)SW_NH, k);
+                        B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
         }
-        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
+        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, ds, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
         CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
     {
-        // hole borders of all thresholds: on the helper stream (if any) beside the bright sweep below
-        hipStream_t ts = side ? side->s : s;
-        if (side) { (void)hipEventRecord(side->dark_done, s); (void)hipStreamWaitEvent(ts, side->dark_done, 0); }
-        else if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ts, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
+        // hole borders of all thresholds and their radii
+        if (!side && (rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
                     B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
-        CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ts, B.sw, n);
-        if (side) (void)hipEventRecord(side->traced, ts);
-        // their radii: still beside the bright sweep
-        CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, ts, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
+        CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
+        CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
                     (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
-        if (side) (void)hipEventRecord(side->medians, ts);
+        if (side) (void)hipEventRecord(side->medians, ds);
     }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
+    (void)hipMemsetAsync(B.htime, 0xFF, total, s);
     CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
-                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0);
+                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0, B.hpar, B.htime);
     for (int j = 0; j < NTHR; j++) {
         const int k = NTHR - 1 - j, thr = 50 + 10 * k;
         const int hi = j == 0 ? 255 : thr + 10;
         CPE_KLAUNCH(k_sw_unite<false>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, k + 1, (const FrameState *)st,
                     (const int *)B.sw, (const int *)B.bk, B.lab2);
         CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
-                    (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, k);
+                    (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
         if (j > 0)
             CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
-                        (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, 0,
-                        B.bl, B.sw, (int)SW_NL, k);
-        CPE_KLAUNCH(k_enclosed, dim3(MAXSWL / 64, n), dim3(64), 0, s, (const int2 *)B.hl, (const int *)B.sw, k, (const int *)B.lab2, h, w, B.cnt2);
-        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, s, B.bl, B.sw, (int)SW_NL, k, h, w, (const int *)B.cnt2, (int2 *)nullptr, st);
+                        (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, j,
+                        B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
-    if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
+    if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
+    CPE_KLAUNCH(k_enclosed_all, dim3(n), dim3(ENC_NT), 0, s, (const int2 *)B.hl, B.bl, (const int *)B.sw, (const int *)B.hpar,
+                (const uint8_t *)B.htime, h, w, B.cnt2);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
-    if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
     CPE_KLAUNCH(k_blob_median, dim3(32, n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
                 (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
     {
