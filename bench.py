@@ -108,7 +108,8 @@ def main():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--frames', type=int, default=4096, help='stereo frames per GPU per step')
-    ap.add_argument('--chunk', type=int, default=128, help='stereo frames per kernel batch (workspace size)')
+    ap.add_argument('--chunk', type=int, default=0,
+                    help='stereo frames per kernel batch (workspace size); 0 = 256 at 1920x1200 (~90 GB of workspace), 64 at 3840x2160')
     ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes per GPU (cycled with fresh noise)')
     ap.add_argument('--fit-mode', choices=['nm', 'lm'], default='nm',
                     help='nm = fminsearch clone (reference behaviour, default); lm = Levenberg-Marquardt fast mode')
@@ -129,6 +130,8 @@ def main():
     global H, W, BYTES_PER_FRAME
     W, H = (int(v) for v in args.size.split('x'))
     BYTES_PER_FRAME = 2 * (H * W + 1024 * 24)
+    if args.chunk <= 0:
+        args.chunk = 256 if H * W <= 1920 * 1200 else 64
     F = args.frames
     # ---- synthetic inputs, resident in HBM: `unique` rendered scenes, every frame gets its own sensor noise
     U = min(args.unique, F)
