@@ -256,80 +256,104 @@ __global__ __launch_bounds__(256) void k_or_and(const uint8_t *__restrict__ a, c
 }
 
 // a-5 tail + a-6 head in one kernel:  roi = open3x3(mask & circle_mask & mask_contour)  (util_cylinder.py:1995-2005),
-// base = close3x3(roi) (:150-152).  64x32 tile with a 4-px apron in LDS; out-of-image pixels never erode / dilate.
-constexpr int RT_X = 64, RT_Y = 32, RAP = 4;
-constexpr int RW = RT_X + 2 * RAP, RH = RT_Y + 2 * RAP;
+// base = close3x3(roi) (:150-152); out-of-image pixels never erode / dilate.  Bit rows like k_open20_joints: a workgroup
+// holds a band of RB_R + 8 rows (all columns) as 64-pixel words in LDS and runs the four 3x3 passes on words (3 taps
+// along the row by shifts, 3 rows by AND / OR).  mask_contour is zero outside the region rectangle, so only its pixels
+// are read: everything else packs as zero, and bands further than 4 rows from it are written as zeros straight away.
+constexpr int RB_R = 64, RB_AP = 4, RB_ROWS = RB_R + 2 * RB_AP;
 __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m, const uint8_t *__restrict__ cm,
-                                                  const uint8_t *__restrict__ mc, int h, int w, int tiles_x, int tiles_y,
+                                                  const uint8_t *__restrict__ mc, int h, int w, int bands,
                                                   const FrameState *__restrict__ st, uint8_t *__restrict__ roi,
                                                   uint8_t *__restrict__ base)
 {
-    __shared__ uint8_t a[RH * RW], b[RH * RW];   // 0 / 1, 2 = outside the image
+    extern __shared__ unsigned long long s_rb[];
+    const int WW = (w + 63) >> 6;
+    unsigned long long *buf0 = s_rb, *buf1 = s_rb + (size_t)RB_ROWS * WW;
     const int t = threadIdx.x;
-    const int tiles = tiles_x * tiles_y;
-    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
-    const int gx0 = (tt % tiles_x) * RT_X, gy0 = (tt / tiles_x) * RT_Y;
+    const int f = blockIdx.x / bands, band = blockIdx.x - f * bands;
+    const int y0 = band * RB_R;
     const size_t N = (size_t)h * w;
-    {
-        // mask_contour is zero outside the region rectangle; opening cannot add pixels and closing stays inside the
-        // dilation, so both outputs are zero further than one pixel from the rectangle
-        const int *r = st[f].rect;
-        const bool nohull = st[f].status == CPE_ST_NO_REGION;
-        if (nohull || gx0 > r[0] + r[2] + 1 || gx0 + RT_X < r[0] - 1 || gy0 > r[1] + r[3] + 1 || gy0 + RT_Y < r[1] - 1) {
-            for (int i = t; i < RT_Y * RT_X; i += 256) {
-                int ry = i / RT_X, rx = i - ry * RT_X;
-                int y = gy0 + ry, x = gx0 + rx;
-                if (y < h && x < w) { roi[f * N + (size_t)y * w + x] = 0; base[f * N + (size_t)y * w + x] = 0; }
-            }
-            return;
+    const int *rc = st[f].rect;
+    const int rx0 = rc[0], ry0 = rc[1], rx1 = rc[0] + rc[2] - 1, ry1 = rc[1] + rc[3] - 1;
+    const bool al8 = ((w & 7) == 0) && ((((size_t)m | (size_t)cm | (size_t)mc | (size_t)roi | (size_t)base) & 7) == 0);
+    const int per_row = WW * 8;
+    auto store8 = [&](uint8_t *dst, size_t o, int x0, unsigned bits) {
+        if (al8) *reinterpret_cast<unsigned long long *>(dst + o) = bytes_of_bits8(bits);
+        else for (int b = 0; b < 8 && x0 + b < w; b++) dst[o + b] = ((bits >> b) & 1u) ? 255 : 0;
+    };
+    if (st[f].status == CPE_ST_NO_REGION || y0 > ry1 + RB_AP || y0 + RB_R - 1 < ry0 - RB_AP) {
+        for (int i = t; i < RB_R * per_row; i += 256) {
+            const int tr = i / per_row, k = i - tr * per_row;
+            const int y = y0 + tr, x0 = k * 8;
+            if (y >= h || x0 >= w) continue;
+            const size_t o = f * N + (size_t)y * w + x0;
+            store8(roi, o, x0, 0u); store8(base, o, x0, 0u);
         }
+        return;
     }
-    for (int i = t; i < RH * RW; i += 256) {
-        int ry = i / RW, rx = i - ry * RW;
-        int y = gy0 - RAP + ry, x = gx0 - RAP + rx;
-        uint8_t v = 2;
-        if (x >= 0 && x < w && y >= 0 && y < h) {
-            size_t o = f * N + (size_t)y * w + x;
-            v = ((m[o] & cm[o]) & mc[o]) ? 1 : 0;
+    // pack (m & cm & mc) != 0 of the rectangle's pixels; everything else (and outside the image) is zero
+    {
+        uint8_t *pk = reinterpret_cast<uint8_t *>(buf0);
+        for (int i = t; i < RB_ROWS * per_row; i += 256) {
+            const int r = i / per_row, k = i - r * per_row;
+            const int y = y0 - RB_AP + r, x0 = k * 8;
+            unsigned bits = 0u;
+            if (y >= ry0 && y <= ry1 && y >= 0 && y < h && x0 < w && x0 + 7 >= rx0 && x0 <= rx1) {
+                const size_t o = f * N + (size_t)y * w + x0;
+                if (al8) {
+                    unsigned long long v = *reinterpret_cast<const unsigned long long *>(m + o) &
+                                           *reinterpret_cast<const unsigned long long *>(cm + o) &
+                                           *reinterpret_cast<const unsigned long long *>(mc + o);
+                    v = (((v & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | v) & 0x8080808080808080ull;
+                    bits = (unsigned)(((v >> 7) * 0x0102040810204080ull) >> 56);
+                } else {
+                    for (int b = 0; b < 8 && x0 + b < w; b++) bits |= ((m[o + b] & cm[o + b]) & mc[o + b]) ? (1u << b) : 0u;
+                }
+            }
+            pk[i] = (uint8_t)bits;
         }
-        a[i] = v;
     }
     __syncthreads();
-    // one 3x3 pass src -> dst on the ring [r, R-r): mode 0 erode, 1 dilate
-    auto pass = [&](const uint8_t *src, uint8_t *dst, int r, int dil) {
-        for (int i = t; i < RH * RW; i += 256) {
-            int ry = i / RW, rx = i - ry * RW;
-            uint8_t c = src[i];
-            uint8_t o = c;
-            if (c != 2 && ry >= r && ry < RH - r && rx >= r && rx < RW - r) {
-                bool res = !dil;
-                for (int dy = -1; dy <= 1; dy++)
-                    for (int dx = -1; dx <= 1; dx++) {
-                        uint8_t q = src[(ry + dy) * RW + rx + dx];
-                        if (q == 2) continue;
-                        if (dil) res = res || (q == 1);
-                        else res = res && (q == 1);
-                    }
-                o = res ? 1 : 0;
+    // one 3x3 pass on words; pixels outside the image (and rows / words outside the band) are the neutral element
+    auto pass = [&](const unsigned long long *src, unsigned long long *dst, bool dil) {
+        const unsigned long long fill = dil ? 0ull : ~0ull;
+        for (int i = t; i < RB_ROWS * WW; i += 256) {
+            const int r = i / WW, j = i - r * WW;
+            unsigned long long acc = fill;
+#pragma unroll
+            for (int dr = -1; dr <= 1; dr++) {
+                const int rr = r + dr, y = y0 - RB_AP + rr;
+                unsigned long long hres = fill;
+                if (rr >= 0 && rr < RB_ROWS && y >= 0 && y < h) {
+                    const unsigned long long *row = src + (size_t)rr * WW;
+                    const unsigned long long va = row_valid_word(j - 1, w), vb = row_valid_word(j, w), vc = row_valid_word(j + 1, w);
+                    unsigned long long xa = j > 0 ? row[j - 1] : 0ull, xb = row[j], xc = j + 1 < WW ? row[j + 1] : 0ull;
+                    if (!dil) { xa |= ~va; xb |= ~vb; xc |= ~vc; }
+                    const unsigned long long up = (xb >> 1) | (xc << 63), down = (xb << 1) | (xa >> 63);
+                    hres = dil ? (xb | up | down) : (xb & up & down);
+                }
+                acc = dil ? (acc | hres) : (acc & hres);
             }
-            dst[i] = o;
+            const int y = y0 - RB_AP + r;
+            dst[i] = (y >= 0 && y < h) ? (acc & row_valid_word(j, w)) : 0ull;
         }
         __syncthreads();
     };
-    pass(a, b, 1, 0);   // erode
-    pass(b, a, 2, 1);   // dilate -> roi (valid on ring >= 2)
-    for (int i = t; i < RT_Y * RT_X; i += 256) {
-        int ry = i / RT_X, rx = i - ry * RT_X;
-        int y = gy0 + ry, x = gx0 + rx;
-        if (y < h && x < w) roi[f * N + (size_t)y * w + x] = a[(ry + RAP) * RW + rx + RAP] == 1 ? 255 : 0;
-    }
-    pass(a, b, 3, 1);   // dilate
-    pass(b, a, 4, 0);   // erode -> base
-    for (int i = t; i < RT_Y * RT_X; i += 256) {
-        int ry = i / RT_X, rx = i - ry * RT_X;
-        int y = gy0 + ry, x = gx0 + rx;
-        if (y < h && x < w) base[f * N + (size_t)y * w + x] = a[(ry + RAP) * RW + rx + RAP] == 1 ? 255 : 0;
-    }
+    auto emit = [&](const unsigned long long *src, uint8_t *dst) {
+        for (int i = t; i < RB_R * per_row; i += 256) {
+            const int tr = i / per_row, k = i - tr * per_row;
+            const int y = y0 + tr, x0 = k * 8;
+            if (y >= h || x0 >= w) continue;
+            const unsigned bits = (unsigned)(src[(size_t)(tr + RB_AP) * WW + (k >> 3)] >> ((k & 7) * 8)) & 255u;
+            store8(dst, f * N + (size_t)y * w + x0, x0, bits);
+        }
+    };
+    pass(buf0, buf1, false);   // erode
+    pass(buf1, buf0, true);    // dilate -> roi
+    emit(buf0, roi);
+    pass(buf0, buf1, true);    // dilate
+    pass(buf1, buf0, false);   // erode -> base
+    emit(buf0, base);
 }
 
 // ---- joints: polygon-moment centroids inside the region rectangle, in cv2.findContours order ----------
@@ -1123,7 +1147,16 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // a-5 tail, a-6 and the labelling of the expanded masks, once per line direction.  The two directions share
     // nothing but their inputs: the vertical one runs on the helper stream (if any) with the spot chain's label plane.
-    const int tiles_x = (w + RT_X - 1) / RT_X, tiles_y = (h + RT_Y - 1) / RT_Y;
+    const int rb_bands = (h + RB_R - 1) / RB_R;
+    const size_t rb_lds = (size_t)2 * RB_ROWS * ((w + 63) / 64) * 8;
+    CPE_CHECK_ARG(rb_lds <= 160 * 1024, "masks_stage: frame too wide (%d columns)", w);
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roi_base), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
     const size_t bit_words = (size_t)n * h * bit_row_words(w);
     if (side) { (void)hipEventRecord(side->clahe_done, s); (void)hipStreamWaitEvent(side->s, side->clahe_done, 0); }
     for (int which = 0; which < 2; which++) {
@@ -1138,8 +1171,8 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
         uint32_t *bits = B.bits + (which ? bit_words : 0);
         SegRec *segs = B.segs + (size_t)which * n * MAXSEG;
         // roi = open3x3(mask & circle_mask & mask_contour), base = close3x3(roi)
-        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, q, lm, (const uint8_t *)B.cm, (const uint8_t *)B.mc,
-                    h, w, tiles_x, tiles_y, (const FrameState *)st, roi, base);
+        CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * rb_bands)), dim3(256), rb_lds, q, lm, (const uint8_t *)B.cm, (const uint8_t *)B.mc,
+                    h, w, rb_bands, (const FrameState *)st, roi, base);
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
         if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
