@@ -125,6 +125,131 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const uint8_t *__restrict__ i
     }
 }
 
+// ---- word-level walks (rows 16-byte aligned): a thread owns one 64-pixel word column over CCL_STRIP rows, packs each
+// row's membership into a 64-bit mask (SWAR byte compare + multiply gather) and finds the pixels that have work to do --
+// run starts, run-overlap starts -- with shifts and ANDs; only those few touch the label plane.
+constexpr int CCL_STRIP = 8;
+__device__ __forceinline__ unsigned pack8_gt(unsigned long long v, int thr, int invert)   // bit k = ((byte k > thr) != invert)
+{
+    const unsigned long long H = 0x8080808080808080ull, O = 0x0101010101010101ull;
+    const unsigned long long g = ((v & ~H) + (unsigned long long)(0x7f - (thr & 0x7f)) * O) & H;   // low 7 bits > low 7 bits of thr
+    unsigned long long res = (thr < 128) ? ((v & H) | g) : ((v & H) & g);
+    if (invert) res ^= H;
+    return (unsigned)(((res >> 7) * 0x0102040810204080ull) >> 56);
+}
+__device__ __forceinline__ unsigned long long pack_row64(const uint8_t *row, int x0, int w, int thr, int invert)
+{
+    unsigned long long bits = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int x = x0 + 16 * c;
+        if (x < w) {   // w % 16 == 0: the 16 pixels are all inside
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + x);
+            const unsigned long long lo = v.x | ((unsigned long long)v.y << 32), hi = v.z | ((unsigned long long)v.w << 32);
+            bits |= (unsigned long long)(pack8_gt(lo, thr, invert) | (pack8_gt(hi, thr, invert) << 8)) << (16 * c);
+        }
+    }
+    return bits;
+}
+__device__ __forceinline__ unsigned long long col_mask64(int x0, int lo, int hi)   // pixels x0 + b with lo <= x0 + b <= hi
+{
+    const int a = max(lo - x0, 0), b = min(hi - x0, 63);
+    if (b < a) return 0ull;
+    const unsigned long long m = (b == 63) ? ~0ull : ((1ull << (b + 1)) - 1ull);
+    return m & ~((1ull << a) - 1ull);
+}
+
+// same unions as k_ccl_merge
+__global__ __launch_bounds__(256) void k_ccl_merge64(const uint8_t *__restrict__ img, int h, int w, int thr,
+                                                     int invert, int conn8, const FrameState *__restrict__ st, int use_rect,
+                                                     int *__restrict__ L)
+{
+    const int WW = (w + 63) >> 6, strips = (h + CCL_STRIP - 1) / CCL_STRIP;
+    const size_t f = blockIdx.y;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= WW * strips) return;
+    const int sy = gi / WW, j = gi - sy * WW;
+    const Rect r = get_rect(st, f, use_rect, h, w);
+    const int x0 = j * 64;
+    if (r.x1 < r.x0 || x0 > r.x1 || x0 + 63 < r.x0) return;
+    const int ya = max(sy * CCL_STRIP, r.y0 + 1), yb = min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1);
+    if (ya > yb) return;
+    const size_t N = (size_t)h * w;
+    const uint8_t *im = img + f * N;
+    int *Lf = L + f * N;
+    const unsigned long long cmask = col_mask64(x0, r.x0, r.x1);
+    const bool hasL = x0 - 1 >= r.x0, hasR = x0 + 64 <= r.x1;
+    const uint8_t *row = im + (size_t)(ya - 1) * w;
+    unsigned long long A = pack_row64(row, x0, w, thr, invert) & cmask;
+    unsigned long long aL = (hasL && pred(row, x0 - 1, thr, invert)) ? 1ull : 0ull, aR = (hasR && pred(row, x0 + 64, thr, invert)) ? 1ull : 0ull;
+    for (int y = ya; y <= yb; y++) {
+        row = im + (size_t)y * w;
+        const unsigned long long C = pack_row64(row, x0, w, thr, invert) & cmask;
+        const unsigned long long cL = (hasL && pred(row, x0 - 1, thr, invert)) ? 1ull : 0ull, cR = (hasR && pred(row, x0 + 64, thr, invert)) ? 1ull : 0ull;
+        if (C) {
+            const unsigned long long Cs = (C << 1) | cL, As = (A << 1) | aL;            // left, up-left
+            const int base = y * w + x0;
+            unsigned long long m = C & A & ~(Cs & As);
+            while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(Lf, base + b, base + b - w); }
+            if (conn8) {
+                const unsigned long long Cr = (C >> 1) | (cR << 63), Ar = (A >> 1) | (aR << 63);   // right, up-right
+                const unsigned long long nu = C & ~A;
+                m = nu & Ar & ~Cr;
+                while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(Lf, base + b, base + b - w + 1); }
+                m = nu & As & ~Cs;
+                while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(Lf, base + b, base + b - w - 1); }
+            }
+        }
+        A = C; aL = cL; aR = cR;
+    }
+}
+
+// component list of a roots-only pass: only the first pixel of a horizontal run can carry its own index
+__global__ __launch_bounds__(256) void k_ccl_roots64(const uint8_t *__restrict__ img, int h, int w, int thr, int invert,
+                                                     FrameState *__restrict__ st, int use_rect, const int *__restrict__ L,
+                                                     int *__restrict__ roots, int cnt_sel)
+{
+    const int WW = (w + 63) >> 6, strips = (h + CCL_STRIP - 1) / CCL_STRIP;
+    const size_t f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    const Rect r = get_rect(st, f, use_rect, h, w);
+    const size_t N = (size_t)h * w;
+    const uint8_t *im = img + f * N;
+    const int *Lf = L + f * N;
+    const int sy = gi / WW, j = gi - sy * WW, x0 = j * 64;
+    const bool live = gi < WW * strips && !(r.x1 < r.x0 || x0 > r.x1 || x0 + 63 < r.x0);
+    const int ya = max(sy * CCL_STRIP, r.y0), yb = live ? min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1) : -1;
+    const unsigned long long cmask = col_mask64(x0, r.x0, r.x1);
+    const bool hasL = x0 - 1 >= r.x0;
+    for (int k = 0; k < CCL_STRIP; k++) {     // wave-uniform trip count: the appends below are wavefront collectives
+        const int y = ya + k;
+        unsigned long long starts = 0;
+        if (y <= yb) {
+            const uint8_t *row = im + (size_t)y * w;
+            const unsigned long long C = pack_row64(row, x0, w, thr, invert) & cmask;
+            const unsigned long long cL = (C & 1ull) && hasL && pred(row, x0 - 1, thr, invert) ? 1ull : 0ull;
+            starts = C & ~((C << 1) | cL);
+        }
+        while (__ballot(starts != 0)) {
+            int i = -1;
+            if (starts) { const int b = __ffsll((long long)starts) - 1; starts &= starts - 1; i = y * w + x0 + b; }
+            const bool cand = i >= 0 && Lf[i] == i;
+            const unsigned long long rb = __ballot(cand);
+            if (!rb) continue;
+            int base = 0;
+            const int leader = __ffsll((long long)rb) - 1;
+            if (lane == leader) base = atomicAdd(root_counter(st[f], cnt_sel), __popcll(rb));
+            base = __shfl(base, leader, 64);
+            if (cand) {
+                const int q = base + __popcll(rb & ((1ull << lane) - 1ull));
+                if (q < MAXROOTS) roots[f * MAXROOTS + q] = i;
+                else set_overflow(st[f], OVF_ROOTS);
+            }
+        }
+    }
+}
+
 // components of the set that reach the border of the working rectangle: touch[root] = 1
 __global__ __launch_bounds__(256) void k_ccl_touch(const int *__restrict__ L, int n, int h, int w,
                                                    const FrameState *__restrict__ st, int use_rect,
@@ -421,15 +546,23 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0, cnt_sel);
     CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                 count_mode ? cnt : (int *)nullptr, sparse);
-    CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
-                (const FrameState *)st, use_rect, L);
+    // rows that start on 16-byte boundaries: word-level walks
+    const bool words = (w % 16 == 0) && (((size_t)img & 15) == 0);
+    const dim3 gwords((unsigned)((((w + 63) / 64) * ((h + CCL_STRIP - 1) / CCL_STRIP) + 255) / 256), n);
+    if (words)
+        CPE_KLAUNCH(k_ccl_merge64, gwords, dim3(256), 0, s, img, h, w, thr, invert, conn8, (const FrameState *)st, use_rect, L);
+    else
+        CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
+                    (const FrameState *)st, use_rect, L);
     if (holes_only) {
         (void)hipMemsetAsync(touch, 0, total, s);
         int per = 2 * w + 2 * h;
         CPE_KLAUNCH(k_ccl_touch, dim3((n * per + 255) / 256), dim3(256), 0, s, (const int *)L, n, h, w, (const FrameState *)st,
                     use_rect, touch);
     }
-    if (flags & 1)
+    if ((flags & 1) && words)
+        CPE_KLAUNCH(k_ccl_roots64, gwords, dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L, roots, cnt_sel);
+    else if (flags & 1)
         CPE_KLAUNCH(k_ccl_roots4, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L,
                     roots, cnt_sel);
     else if (!(flags & 2))

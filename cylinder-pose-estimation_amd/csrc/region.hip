@@ -86,27 +86,35 @@ __global__ __launch_bounds__(256) void k_clahe_lut(unsigned int *__restrict__ hi
     lut[(size_t)blockIdx.x * 256 + t] = (uint8_t)sat_u8((int)rintf((float)sh[t] * g.lutScale));
 }
 
-// grid = (ceil(N / 4096), n), 16 pixels per thread.  Also accumulates the bounding box of the result's pixels > 50 (the
-// lowest threshold of the blob detector) in nrect[f]: the working rectangle of the whole sweep comes with the pass that
-// writes the image.  (4096 pixels per workgroup keep the same-address atomics on the box rare.)
+// grid = (ceil(N / CLAHE_BLK_PX), n).  The frame's 16 tile LUTs (4 KB) sit in LDS; a thread takes 4 neighbouring pixels
+// per step (one dword in, one dword out when rows allow).  Also accumulates the bounding box of the result's pixels > 50
+// (the lowest threshold of the blob detector) in nrect[f]: the working rectangle of the whole sweep comes with the pass
+// that writes the image.  (Many pixels per workgroup keep the same-address atomics on the box rare.)
+constexpr int CLAHE_BLK_PX = 8192;
 __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ gray, int h, int w,
                                                      ClaheGeom g, const uint8_t *__restrict__ lut,
                                                      uint8_t *__restrict__ dst, int *__restrict__ nrect)
 {
     __shared__ int s_b[4];
+    __shared__ uint8_t s_lut[16 * 256];
+    __shared__ uint8_t s_lab[256];
     const int N = h * w;
     const size_t f = blockIdx.y;
     if (threadIdx.x == 0) { s_b[0] = INT_MAX; s_b[1] = INT_MAX; s_b[2] = -1; s_b[3] = -1; }
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lut + f * 16 * 256);   // tilesX = tilesY = 4
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(s_lut);
+        for (int i = threadIdx.x; i < 16 * 256 / 4; i += 256) d32[i] = src[i];
+        s_lab[threadIdx.x] = c_lab_l[threadIdx.x];
+    }
     __syncthreads();
     int mnx = INT_MAX, mny = INT_MAX, mxx = -1, mxy = -1;
     const float inv_tw = 1.0f / g.tw, inv_th = 1.0f / g.th;
-    const uint8_t *lf = lut + f * g.tilesX * g.tilesY * 256;
-#pragma unroll 4
-    for (int k = 0; k < 16; k++) {
-        const int i = blockIdx.x * 4096 + k * 256 + threadIdx.x;
-        if (i >= N) break;
-        const size_t gi = f * (size_t)N + i;
-        int y = i / w, x = i - y * w;
+    const uint8_t *gf = gray + f * (size_t)N;
+    uint8_t *df = dst + f * (size_t)N;
+    const bool al4 = ((((size_t)gf | (size_t)df) & 3) == 0);
+    auto one = [&](int i, int v0) -> int {
+        const int y = i / w, x = i - y * w;
         float tyf = y * inv_th - 0.5f;
         int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
         float ya = tyf - ty1, ya1 = 1.0f - ya;
@@ -117,14 +125,27 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
         float xa = txf - tx1, xa1 = 1.0f - xa;
         tx1 = max(tx1, 0);
         tx2 = min(tx2, g.tilesX - 1);
-        int v = c_lab_l[gray[gi]];
-        const uint8_t *p1 = lf + (size_t)(ty1 * g.tilesX) * 256, *p2 = lf + (size_t)(ty2 * g.tilesX) * 256;
+        const int v = s_lab[v0];
+        const uint8_t *p1 = s_lut + (ty1 * g.tilesX) * 256, *p2 = s_lut + (ty2 * g.tilesX) * 256;
         float a = (float)p1[tx1 * 256 + v] * xa1, b = (float)p1[tx2 * 256 + v] * xa;
         float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
         float res = (a + b) * ya1 + (c + d) * ya;
         const int out = sat_u8((int)rintf(res));
-        dst[gi] = (uint8_t)out;
         if (out > 50) { mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y); }
+        return out;
+    };
+    for (int k = 0; k < CLAHE_BLK_PX / 1024; k++) {
+        const int i0 = blockIdx.x * CLAHE_BLK_PX + k * 1024 + threadIdx.x * 4;
+        if (i0 >= N) break;
+        if (al4 && i0 + 4 <= N) {
+            const uint32_t v4 = *reinterpret_cast<const uint32_t *>(gf + i0);
+            uint32_t o4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) o4 |= (uint32_t)one(i0 + q, (v4 >> (8 * q)) & 255u) << (8 * q);
+            *reinterpret_cast<uint32_t *>(df + i0) = o4;
+        } else {
+            for (int q = 0; q < 4 && i0 + q < N; q++) df[i0 + q] = (uint8_t)one(i0 + q, gf[i0 + q]);
+        }
     }
     if (__ballot(mxx >= 0)) {
         for (int off = 32; off >= 1; off >>= 1) {
@@ -1348,7 +1369,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     const int strips = 8;
     CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist);
     CPE_KLAUNCH(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
-    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + 4095) / 4096), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect);
+    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + CLAHE_BLK_PX - 1) / CLAHE_BLK_PX), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
     if (side) {   // the 17 one-bit planes only need the CLAHE image
