@@ -79,6 +79,14 @@ struct RegionBuffers {
     unsigned long long *best;
     int *lohi, *hull;
 };
+// grid.x of the kernels that walk a per-frame list (components, blobs, fragments) in turns: enough workgroups per frame
+// to fill the chip when the batch is small, few when it is large (a grid sized for the list capacity would be mostly
+// empty workgroups: hundreds of thousands of them cost more than the work)
+inline unsigned frame_waves(int lists, int lo, int hi)
+{
+    const int v = 16384 / (lists > 0 ? lists : 1);
+    return (unsigned)(v < lo ? lo : (v > hi ? hi : v));
+}
 // optional helper stream of the region stage: the hole borders are followed while the bright sweep runs
 struct RegionSide { hipStream_t s; hipEvent_t clahe_done, dark_done, traced, medians; };
 struct MaskBuffers {

@@ -362,26 +362,27 @@ __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restric
                                                         int *__restrict__ jtmp /* n*MAXJ*3 */)
 {
     const int f = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (st[f].status != CPE_ST_OK) return;
-    if (k >= min(st[f].n_roots_p, MAXROOTS)) return;
     const size_t N = (size_t)h * w;
-    const int root = roots[(size_t)f * MAXROOTS + k];
-    MaskPred nz{jm + f * N, w, h};
-    StatVisitor sv;
-    if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { set_overflow(st[f], OVF_TRACE); return; }
-    sv.finish();
-    double m00, m10, m01;
-    moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
-    if (m00 == 0) return;
-    int cx = (int)(m10 / m00), cy = (int)(m01 / m00);
-    atomicAdd(&st[f].n_joints_all, 1);
-    const int *r = st[f].rect;
-    if (!(r[0] <= cx && cx < r[0] + r[2] && r[1] <= cy && cy < r[1] + r[3])) return;
-    int q = atomicAdd(&st[f].n_joints, 1);
-    if (q >= MAXJ) { set_overflow(st[f], OVF_JOINTS); return; }
-    int *o = jtmp + ((size_t)f * MAXJ + q) * 3;
-    o[0] = cx; o[1] = cy; o[2] = root;
+    const int ncomp = min(st[f].n_roots_p, MAXROOTS);
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {
+        const int root = roots[(size_t)f * MAXROOTS + k];
+        MaskPred nz{jm + f * N, w, h};
+        StatVisitor sv;
+        if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { set_overflow(st[f], OVF_TRACE); continue; }
+        sv.finish();
+        double m00, m10, m01;
+        moments_from_sums(sv.a00, sv.a10, sv.a01, m00, m10, m01);
+        if (m00 == 0) continue;
+        int cx = (int)(m10 / m00), cy = (int)(m01 / m00);
+        atomicAdd(&st[f].n_joints_all, 1);
+        const int *r = st[f].rect;
+        if (!(r[0] <= cx && cx < r[0] + r[2] && r[1] <= cy && cy < r[1] + r[3])) continue;
+        int q = atomicAdd(&st[f].n_joints, 1);
+        if (q >= MAXJ) { set_overflow(st[f], OVF_JOINTS); continue; }
+        int *o = jtmp + ((size_t)f * MAXJ + q) * 3;
+        o[0] = cx; o[1] = cy; o[2] = root;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_joint_sort(FrameState *__restrict__ st, const int *__restrict__ jtmp,
@@ -485,18 +486,19 @@ __global__ __launch_bounds__(64) void k_spot_area(const uint8_t *__restrict__ g1
                                                   unsigned long long *__restrict__ best)
 {
     const int f = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(st[f].n_roots_s, MAXROOTS)) return;   // (runs beside the region stage: no look at st[].status here)
     const size_t N = (size_t)h * w;
-    const int root = roots[(size_t)f * MAXROOTS + k];
-    ThreshPred nz{g19 + f * N, w, h, 240};
-    StatVisitor sv;
-    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
-    sv.finish();
-    long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;
-    // max(contours, key=contourArea): first maximum in list order = latest discovered among equals; area 0 counts
-    unsigned long long key = ((unsigned long long)(a2 + 1) << 24) | (unsigned long long)(root & 0xFFFFFF);
-    atomicMax(&best[f], key);
+    const int ncomp = min(st[f].n_roots_s, MAXROOTS);   // (runs beside the region stage: no look at st[].status here)
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {
+        const int root = roots[(size_t)f * MAXROOTS + k];
+        ThreshPred nz{g19 + f * N, w, h, 240};
+        StatVisitor sv;
+        if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); continue; }
+        sv.finish();
+        long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;
+        // max(contours, key=contourArea): first maximum in list order = latest discovered among equals; area 0 counts
+        unsigned long long key = ((unsigned long long)(a2 + 1) << 24) | (unsigned long long)(root & 0xFFFFFF);
+        atomicMax(&best[f], key);
+    }
 }
 
 struct VertVisitor {
@@ -874,18 +876,18 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
                                                   SegRec *__restrict__ segs /* n*MAXSEG */)
 {
     const int f = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (st[f].status != CPE_ST_OK) return;
-    if (k >= min(*root_counter(st[f], cnt_sel), MAXROOTS)) return;
-    const int root = roots[(size_t)f * MAXROOTS + k];
     __shared__ unsigned long long s_win[BW_ROWS * 64];
+    const int ncomp = min(*root_counter(st[f], cnt_sel), MAXROOTS);
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {   // components in turns, one per lane
+    const int root = roots[(size_t)f * MAXROOTS + k];
     const int ws = bit_row_words(w);
     BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
     float pts[2 * MAXVS];
     SegVisitor sv{pts, MAXVS};
-    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
+    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); continue; }
     const int n = sv.n;
-    if (n < MINV || n > MAXVS) return;
+    if (n < MINV || n > MAXVS) continue;
     // get_pca_endpoints
     float mx = 0, my = 0;
     for (int i = 0; i < n; i++) { mx += pts[2 * i]; my += pts[2 * i + 1]; }
@@ -914,13 +916,14 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     float p1x = pts[2 * imin], p1y = pts[2 * imin + 1], p2x = pts[2 * imax], p2y = pts[2 * imax + 1];
     float dx = p2x - p1x, dy = p2y - p1y;
     float length = (float)hypot((double)dx, (double)dy);
-    if (length < 1e-8) return;
+    if (length < 1e-8) continue;
     float at = (float)atan2((double)dy, (double)dx);
     float deg = at * (float)(180.0 / 3.14159265358979323846);
     int q = atomicAdd(&st[f].n_seg[which], 1);
-    if (q >= MAXSEG) { set_overflow(st[f], OVF_SEGS); return; }
+    if (q >= MAXSEG) { set_overflow(st[f], OVF_SEGS); continue; }
     SegRec &r = segs[(size_t)f * MAXSEG + q];
     r.p1x = p1x; r.p1y = p1y; r.p2x = p2x; r.p2y = p2y; r.angle = -deg; r.len = length; r.valid = 1;
+    }
 }
 
 // median angle (np.median of float32) and maximum length per frame
@@ -969,13 +972,15 @@ __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ 
     const int f = blockIdx.y, t = threadIdx.x;
     FrameState &S = st[f];
     if (S.status != CPE_ST_OK) return;
-    const int seg = blockIdx.x >> 1, e = blockIdx.x & 1;
-    if (seg >= min(S.n_seg[which], MAXSEG)) return;
+    const int njobs = 2 * min(S.n_seg[which], MAXSEG);
+    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {   // (fragment, end point) pairs in turns
+    const int seg = job >> 1, e = job & 1;
     const SegRec r = segs[(size_t)f * MAXSEG + seg];
     const float glen = S.glen[which], gang = S.gang[which];
-    if ((double)r.len > 0.8 * (double)glen) return;
+    if ((double)r.len > 0.8 * (double)glen) continue;
     const int ks = fixed_ks > 0 ? fixed_ks : 91 + S.r0;
     if (ks > MAXKS) { if (t == 0) set_overflow(S, OVF_KERNEL); return; }
+    __syncthreads();   // the previous job's readers of dil / koff / ppix are done
     const float ak = fabsf(r.angle - gang) > 5.0f ? gang : r.angle;
     const int a = ks / 2, half = 7;
     const size_t N = (size_t)h * w;
@@ -1045,6 +1050,7 @@ __global__ __launch_bounds__(256) void k_seg_expand(const uint8_t *__restrict__ 
                 if (!v) { all = false; break; }
             }
         if (all) ex[(size_t)gy * w + gx] = 255;
+    }
     }
 }
 
@@ -1126,7 +1132,7 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
                     t19, (const FrameState *)st, B.g19);
     }
     if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab_s, B.roots_s, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 2)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_spot_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.g19, h, w, B.roots_s, st, B.best_s);
+    CPE_KLAUNCH(k_spot_area, dim3(4, n), dim3(64), 0, s, B.g19, h, w, B.roots_s, st, B.best_s);
     (void)hipMemsetAsync(B.cm, 255, total, s);
     CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm, planar);
     CPE_CHECK_LAUNCH("spot_stage");
@@ -1143,7 +1149,7 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
     // joints
-    CPE_KLAUNCH(k_joint_centroids, dim3(MAXROOTS / 64, n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp);
+    CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp);
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // a-5 tail, a-6 and the labelling of the expanded masks, once per line direction.  The two directions share
     // nothing but their inputs: the vertical one runs on the helper stream (if any) with the spot chain's label plane.
@@ -1175,12 +1181,12 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
                     h, w, rb_bands, (const FrameState *)st, roi, base);
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
-        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
-        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(MAXROOTS / 64, n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 16, 64), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(frame_waves(n, 16, 64), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
         CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, q, st, which, (const SegRec *)segs);
         (void)hipMemsetAsync(tmp, 0, total, q);
-        if (planar) CPE_KLAUNCH(k_seg_expand<EXP_MAXKS_PLANE>, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 201);
-        else CPE_KLAUNCH(k_seg_expand<EXP_MAXKS>, dim3(MAXSEG * 2, n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 0);
+        if (planar) CPE_KLAUNCH(k_seg_expand<EXP_MAXKS_PLANE>, dim3(frame_waves(n, 32, 256), n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 201);
+        else CPE_KLAUNCH(k_seg_expand<EXP_MAXKS>, dim3(frame_waves(n, 32, 256), n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 0);
         CPE_KLAUNCH(k_or_and, dim3((unsigned)(((size_t)h * w + 16383) / 16384), n), dim3(256), 0, q, (const uint8_t *)tmp, (const uint8_t *)base,
                     (const uint8_t *)B.mc, h, w, (const FrameState *)st, exp);
         CPE_CHECK_LAUNCH("masks_stage expand");

@@ -263,20 +263,16 @@ struct StoreVisitor {
     __device__ __forceinline__ bool stop() const { return false; }
 };
 
+// one border per lane; a few wavefronts per (frame, threshold) take the list entries in turns (a grid sized for the list
+// capacity would be millions of empty workgroups; see frame_waves)
 template <int is_hole>
-__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w,
-                                                   const int2 *__restrict__ lists, int cnt_base,
-                                                   FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
-                                                   int *__restrict__ blob_d_all, double *__restrict__ dists_all,
-                                                   const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all,
-                                                   unsigned short *__restrict__ blob_ch_all, int maxch, int maxdf)
+__device__ __forceinline__ void blob_trace_one(int f, int slot, int k, int h, int w, const int2 *__restrict__ lists,
+                                               FrameState *__restrict__ st, int *__restrict__ S, BlobRec *__restrict__ blobs_all,
+                                               int *__restrict__ blob_d_all, double *__restrict__ dists_all,
+                                               const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all,
+                                               unsigned short *__restrict__ blob_ch_all, int maxch, int maxdf,
+                                               unsigned long long *s_win, unsigned short *s_ids)
 {
-    __shared__ unsigned long long s_win[BW_ROWS * 64];
-    __shared__ unsigned short s_ids[CH_DIRECT * 64];
-    const int f = blockIdx.y, slot = blockIdx.z;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    int *S = sw + (size_t)f * SW_STRIDE;
-    if (k >= min(S[cnt_base + slot], MAXSWL)) return;
     const int2 e = lists[((size_t)f * NTHR + slot) * MAXSWL + k];
     const int root = e.x;
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
@@ -330,6 +326,24 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     BlobRec &b = blobs[bi];
     b.x = cx; b.y = cy; b.r = 0;
     b.key = root;   // discovery position of the border in the raster scan
+}
+
+template <int is_hole>
+__global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ cl, int h, int w,
+                                                   const int2 *__restrict__ lists, int cnt_base,
+                                                   FrameState *__restrict__ st, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
+                                                   int *__restrict__ blob_d_all, double *__restrict__ dists_all,
+                                                   const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all,
+                                                   unsigned short *__restrict__ blob_ch_all, int maxch, int maxdf)
+{
+    __shared__ unsigned long long s_win[BW_ROWS * 64];
+    __shared__ unsigned short s_ids[CH_DIRECT * 64];
+    const int f = blockIdx.y, slot = blockIdx.z;
+    int *S = sw + (size_t)f * SW_STRIDE;
+    const int cnt = min(S[cnt_base + slot], MAXSWL);
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < cnt; k += gridDim.x * 64)
+        blob_trace_one<is_hole>(f, slot, k, h, w, lists, st, S, blobs_all, blob_d_all, dists_all, bits, pool_all, blob_ch_all, maxch, maxdf,
+                                s_win, s_ids);
 }
 
 // k-th smallest (0-based) of n values read through get(i) by one wavefront, for any n: the candidate set is narrowed by
@@ -1134,19 +1148,20 @@ __global__ __launch_bounds__(64) void k_region_area(const uint32_t *__restrict__
 {
     __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int f = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(st[f].n_roots, MAXROOTS)) return;
-    const int root = roots[(size_t)f * MAXROOTS + k];
+    const int ncomp = min(st[f].n_roots, MAXROOTS);
     const int ws = bit_row_words(w);
-    BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
-    StatVisitor sv;
-    if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); return; }
-    sv.finish();
-    long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;  // 2 * area, exact
-    if (a2 <= 0) return;
-    // maximise (area, root): the later-discovered contour comes first in OpenCV's list
-    unsigned long long key = ((unsigned long long)a2 << 24) | (unsigned long long)(root & 0xFFFFFF);
-    atomicMax(&best[f], key);
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {   // components in turns, one per lane
+        const int root = roots[(size_t)f * MAXROOTS + k];
+        BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
+        StatVisitor sv;
+        if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); continue; }
+        sv.finish();
+        long long a2 = sv.a00 < 0 ? -sv.a00 : sv.a00;  // 2 * area, exact
+        if (a2 <= 0) continue;
+        // maximise (area, root): the later-discovered contour comes first in OpenCV's list
+        unsigned long long key = ((unsigned long long)a2 << 24) | (unsigned long long)(root & 0xFFFFFF);
+        atomicMax(&best[f], key);
+    }
 }
 
 struct HullVisitor {
@@ -1382,7 +1397,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(MAXSWL / 64, n, NTHR), gbk(SW_GRID, n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(frame_waves(n * NTHR, 8, MAXSWL / 64), n, NTHR), gbk(SW_GRID, n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1427,7 +1442,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
                     B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
         CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
-        CPE_KLAUNCH(k_blob_median, dim3(128, n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
+        CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 16, 128), n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
                     (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
         if (side) (void)hipEventRecord(side->medians, ds);
     }
@@ -1454,7 +1469,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                 (const uint8_t *)B.htime, h, w, B.cnt2);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
-    CPE_KLAUNCH(k_blob_median, dim3(32, n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
+    CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 8, 32), n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
                 (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
     {
         // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
@@ -1468,7 +1483,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
     if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     if ((rc = build_bitplanes(B.ext, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
+    CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
     CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
     return CPE_OK;
@@ -1503,7 +1518,7 @@ int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuf
         if (round == 1) CPE_KLAUNCH(k_best_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best);
         if ((rc = ccl_run(img, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(img, n, h, w, thr, 0, 1, B.bits, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_region_area, dim3(MAXROOTS / 64, n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
+        CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
         CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, dst);
         if (round == 0) {
             const int tiles_x = (w + 63) / 64, tiles_y = (h + 31) / 32;
