@@ -870,6 +870,7 @@ struct SegVisitor {
 
 // one thread per fragment: CHAIN_APPROX_SIMPLE vertices (MINV..MAXVS: 5..200 for the cylinder script, 8..700 for the planar
 // one, expand_line_roi's min_pixels / max_pixels) -> PCA end points, angle, length
+constexpr int SEG_LPW = 4;
 template <int MINV, int MAXVS>
 __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ base_bits, int h, int w, int which,
                                                   const int *__restrict__ roots, int cnt_sel, FrameState *__restrict__ st,
@@ -879,7 +880,11 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     if (st[f].status != CPE_ST_OK) return;
     __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int ncomp = min(*root_counter(st[f], cnt_sel), MAXROOTS);
-    for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {   // components in turns, one per lane
+    // Few, long borders: a wavefront steps at the pace of its slowest lane, and with 64 borders in flight nearly every
+    // step waits for some lane's window refill (one memory round trip).  SEG_LPW borders per wavefront keep most steps
+    // LDS-only; the other lanes idle.
+    if (threadIdx.x >= SEG_LPW) return;
+    for (int k = blockIdx.x * SEG_LPW + threadIdx.x; k < ncomp; k += gridDim.x * SEG_LPW) {
     const int root = roots[(size_t)f * MAXROOTS + k];
     const int ws = bit_row_words(w);
     BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
@@ -1181,8 +1186,8 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
                     h, w, rb_bands, (const FrameState *)st, roi, base);
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
-        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 16, 64), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
-        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(frame_waves(n, 16, 64), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
         CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, q, st, which, (const SegRec *)segs);
         (void)hipMemsetAsync(tmp, 0, total, q);
         if (planar) CPE_KLAUNCH(k_seg_expand<EXP_MAXKS_PLANE>, dim3(frame_waves(n, 32, 256), n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 201);
