@@ -906,6 +906,14 @@ __global__ void k_bk_scan(int *sw, int n)
 
 constexpr int SW_GRID = 96;       // workgroups per frame of the kernels that walk one bucket
 
+// list entry of this lane = pixel p (negative: none): is the previous lane's entry its left neighbour in the same row?
+// (wavefront collective; k_sw_new's init pass and k_sw_unite walk the bucket lists with the same lane <-> entry mapping)
+__device__ __forceinline__ bool sw_prelinked(int p, int w, int lane)
+{
+    const int prev = __shfl_up(p, 1, 64);
+    return p >= 0 && lane > 0 && prev == p - 1 && (p % w) != 0;
+}
+
 template <bool DARK>
 __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
                                                   const FrameState *__restrict__ st, const int *__restrict__ sw,
@@ -924,15 +932,19 @@ __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ im
     // neither of the two pixels completing the 2x2 square is a member.
     auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
     auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nb; e += SW_GRID * 256) {
-        const int i = list[e];
+    const int lane = threadIdx.x & 63;
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += SW_GRID * 256) {
+        const int e = e0 + threadIdx.x;
+        const int i = e < nb ? list[e] : -2;
+        const bool prel = sw_prelinked(i, w, lane);   // already points at its run's first pixel (k_sw_new, init pass)
+        if (i < 0) continue;
         const int y = i / w, x = i - y * w;
         const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
         auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
         const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
         const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
         const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
-        if (mL) uf_unite(Pf, i, i - 1);
+        if (mL && !prel) uf_unite(Pf, i, i - 1);
         if (old(vR)) uf_unite(Pf, i, i + 1);
         if (mU && !(mL && mem(vUL))) uf_unite(Pf, i, i - w);
         if (old(vD) && !(mL && mem(vDL))) uf_unite(Pf, i, i + w);
@@ -1006,10 +1018,22 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
     const int *list = bk + f * N + S[SW_BO + bucket];
     int *Pf = P + f * N;
     if (init_bucket >= 1 && init_bucket < NBK) {
-        // the pixels that join at the next step become singletons now (nothing reads their entry before that)
+        // The pixels that join at the next step get their first entry now (nothing reads it before that).  Bucket lists
+        // are in raster order, so neighbouring lanes mostly hold neighbouring pixels of a row: such a run is linked to its
+        // first pixel right here, with plain stores, and k_sw_unite (same lane <-> entry mapping, see sw_prelinked) skips
+        // the union with the left neighbour for them -- about half of all unions, each a memory-side atomic.
         const int ni = S[SW_BS + init_bucket];
         const int *li = bk + f * N + S[SW_BO + init_bucket];
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < ni; e += SW_GRID * 256) { const int p = li[e]; Pf[p] = p; }
+        for (int e0 = blockIdx.x * 256; e0 < ni; e0 += SW_GRID * 256) {
+            const int e = e0 + threadIdx.x;
+            const int p = e < ni ? li[e] : -2;
+            const bool linked = sw_prelinked(p, w, lane);
+            const unsigned long long starts = __ballot(p >= 0 && !linked);
+            if (p >= 0) {
+                const unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+                Pf[p] = p - (lane - (63 - __clzll(m)));
+            }
+        }
     }
     if (bucket < 1) return;
     for (int e0 = blockIdx.x * 256; e0 < nb; e0 += SW_GRID * 256) {
@@ -1419,6 +1443,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
             if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 2)) != CPE_OK) return rc;
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
+            // first entries of the pixels that join at the next step (bucket 1)
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, 0, 1, st, (const int *)B.bk, B.lab, B.cnt,
+                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
             CPE_KLAUNCH(k_sw_old<true>, dim3(MAXROOTS / 256, n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
                         (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
@@ -1427,7 +1454,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const int *)B.sw, (const int *)B.bk, B.lab);
             CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, 0, st, (const int *)B.bk, B.lab, B.cnt,
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, k + 1 < NTHR ? k + 1 : 0, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
             CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)B.hl + (size_t)(k - 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
