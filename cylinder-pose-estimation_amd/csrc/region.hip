@@ -1421,7 +1421,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(frame_waves(n * NTHR, 8, MAXSWL / 64), n, NTHR), gbk(SW_GRID, n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(frame_waves(n * NTHR, 8, MAXSWL / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, MAXSWL / 64), n, NTHR), gbk(SW_GRID, n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1466,7 +1466,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     {
         // hole borders of all thresholds and their radii
         if (!side && (rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_blob_trace<1>, gtrace, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
+        CPE_KLAUNCH(k_blob_trace<1>, gtrace_h, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
                     B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
         CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
         CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 16, 128), n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
