@@ -904,7 +904,7 @@ __global__ void k_bk_scan(int *sw, int n)
     for (int b = 1; b < NBK; b++) { S[SW_BO + b] = off; S[SW_BC + b] = off; off += S[SW_BS + b]; }
 }
 
-constexpr int SW_GRID = 96;       // workgroups per frame of the kernels that walk one bucket
+constexpr int SW_GRID = 96;       // workgroups per frame of the kernels that walk one bucket (fewer in large batches: 24 at 256 images)
 
 // list entry of this lane = pixel p (negative: none): is the previous lane's entry its left neighbour in the same row?
 // (wavefront collective; k_sw_new's init pass and k_sw_unite walk the bucket lists with the same lane <-> entry mapping)
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ im
     auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
     auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
     const int lane = threadIdx.x & 63;
-    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += SW_GRID * 256) {
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
         const int e = e0 + threadIdx.x;
         const int i = e < nb ? list[e] : -2;
         const bool prel = sw_prelinked(i, w, lane);   // already points at its run's first pixel (k_sw_new, init pass)
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
         // the union with the left neighbour for them -- about half of all unions, each a memory-side atomic.
         const int ni = S[SW_BS + init_bucket];
         const int *li = bk + f * N + S[SW_BO + init_bucket];
-        for (int e0 = blockIdx.x * 256; e0 < ni; e0 += SW_GRID * 256) {
+        for (int e0 = blockIdx.x * 256; e0 < ni; e0 += gridDim.x * 256) {
             const int e = e0 + threadIdx.x;
             const int p = e < ni ? li[e] : -2;
             const bool linked = sw_prelinked(p, w, lane);
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
         }
     }
     if (bucket < 1) return;
-    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += SW_GRID * 256) {
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
         const int e = e0 + threadIdx.x;
         const bool isnew = e < nb;
         int i = -1, root = -1;
@@ -1076,8 +1076,9 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
                                                 int *__restrict__ hpar, uint8_t *__restrict__ htime)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
     const int ns = min(src_cnt[f * src_cnt_stride], src_cap);
+    for (int k0 = blockIdx.x * 256; k0 < ns; k0 += gridDim.x * 256) {   // wave-uniform: sw_append is a wavefront collective
+    const int k = k0 + threadIdx.x;
     bool keep = false;
     int r = 0;
     if (k < ns) {
@@ -1095,6 +1096,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
         }
     }
     sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXSWL, &st[f]);
+    }
 }
 
 // freeze the per-component totals of threshold slot `slot` next to the roots: the accumulator plane moves on
@@ -1106,24 +1108,27 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
                                                  int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = k < min(sw[f * SW_STRIDE + cnt_base + slot], MAXSWL);
-    int2 e = make_int2(0, 0);
-    if (valid) {
-        int2 &g = lists[(f * NTHR + slot) * MAXSWL + k];
-        g.y = acc[f * N + g.x];
-        e = g;
-    }
-    if (!trace) return;
-    const bool want = valid && e.y > 3 && e.y < 5000;
+    const int cnt = min(sw[f * SW_STRIDE + cnt_base + slot], MAXSWL);
     const int lane = threadIdx.x & 63;
-    unsigned long long b = __ballot(want);
-    if (!b) return;
-    const int leader = __ffsll((long long)b) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
-    base = __shfl(base, leader, 64);
-    if (want) trace[(f * NTHR + slot) * MAXSWL + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
+    for (int k0 = blockIdx.x * 256; k0 < cnt; k0 += gridDim.x * 256) {
+        const int k = k0 + threadIdx.x;
+        const bool valid = k < cnt;
+        int2 e = make_int2(0, 0);
+        if (valid) {
+            int2 &g = lists[(f * NTHR + slot) * MAXSWL + k];
+            g.y = acc[f * N + g.x];
+            e = g;
+        }
+        if (!trace) continue;
+        const bool want = valid && e.y > 3 && e.y < 5000;
+        unsigned long long b = __ballot(want);
+        if (!b) continue;
+        const int leader = __ffsll((long long)b) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
+        base = __shfl(base, leader, 64);
+        if (want) trace[(f * NTHR + slot) * MAXSWL + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
+    }
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -1421,7 +1426,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(MAXSWL / 256, n), gtrace(frame_waves(n * NTHR, 8, MAXSWL / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, MAXSWL / 64), n, NTHR), gbk(SW_GRID, n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(n, 4, MAXSWL / 256), n), gtrace(frame_waves(n * NTHR, 8, MAXSWL / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, MAXSWL / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1446,7 +1451,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
             // first entries of the pixels that join at the next step (bucket 1)
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, 0, 1, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
-            CPE_KLAUNCH(k_sw_old<true>, dim3(MAXROOTS / 256, n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
+            CPE_KLAUNCH(k_sw_old<true>, dim3(frame_waves(n, 8, MAXROOTS / 256), n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
                         (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
         } else {
