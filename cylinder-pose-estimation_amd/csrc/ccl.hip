@@ -39,16 +39,18 @@ __device__ __forceinline__ Rect get_rect(const FrameState *st, size_t f, int use
     return r;
 }
 
+constexpr int CCL_INIT_ROWS = 16;
 __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ img, int rows_total, int h, int w,
                                                   int thr, int invert, const FrameState *__restrict__ st, int use_rect,
                                                   int *__restrict__ L, int *__restrict__ cnt, int sparse)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int rr = 0; rr < CCL_INIT_ROWS / 4; rr++) {   // CCL_INIT_ROWS rows per workgroup, one wavefront per row and turn
+    const int row = (blockIdx.x * (CCL_INIT_ROWS / 4) + rr) * 4 + (threadIdx.x >> 6);
     if (row >= rows_total) return;
     const int f = row / h, y = row - f * h;
     const Rect r = get_rect(st, f, use_rect, h, w);
-    if (y < r.y0 || y > r.y1 || r.x1 < r.x0) return;
+    if (y < r.y0 || y > r.y1 || r.x1 < r.x0) continue;
     const size_t base = (size_t)row * w;  // == frame * h*w + y*w
     int carry_in = 0, carry_start = 0;
     for (int x0 = r.x0; x0 <= r.x1; x0 += 64) {
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
         } else {
             carry_in = 0;
         }
+    }
     }
 }
 
@@ -333,20 +336,21 @@ __global__ __launch_bounds__(256) void k_ccl_roots4(const uint8_t *__restrict__ 
 //   the image).  Exact prune bounds of the blob detector: a hole of >= 5000 pixels, or a bright component with
 //   >= 5000 interior pixels, has border-polygon area >= 5000 (polygon edges only cross the unit squares of their
 //   own end-point pixels).
+constexpr int CCL_FIN_PX = 8192;
 __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                     int invert, FrameState *__restrict__ st, int use_rect,
                                                     int *__restrict__ L, const uint8_t *__restrict__ touch, int count_mode,
                                                     int *__restrict__ cnt, int *__restrict__ roots, int *__restrict__ nrect, int sparse,
                                                     int noflatten, int cnt_sel)
 {
-    // grid = (ceil(N / 2048), n): a workgroup never straddles two frames, so every wave-level aggregate below is
-    // per frame; 8 steps of 256 pixels per workgroup keep the grid (and its dispatch time) small
+    // grid = (ceil(N / CCL_FIN_PX), n): a workgroup never straddles two frames, so every wave-level aggregate below is
+    // per frame; many steps of 256 pixels per workgroup keep the grid (and its dispatch time) small
     const size_t N = (size_t)h * w;
     const size_t f = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    for (int it = 0; it < 8; it++) {
-    const int i = blockIdx.x * 2048 + it * 256 + threadIdx.x;
-    if ((size_t)(blockIdx.x * 2048 + it * 256) >= N) break;
+    for (int it = 0; it < CCL_FIN_PX / 256; it++) {
+    const int i = blockIdx.x * CCL_FIN_PX + it * 256 + threadIdx.x;
+    if ((size_t)(blockIdx.x * CCL_FIN_PX + it * 256) >= N) break;
     const size_t gi = f * N + (size_t)i;
     int root = -1, x = 0, y = 0;
     if ((size_t)i < N) {
@@ -544,7 +548,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     const int rows = n * h;
     CPE_LAUNCH_BEGIN();
     if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0, cnt_sel);
-    CPE_KLAUNCH(k_ccl_init, dim3((rows + 3) / 4), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
+    CPE_KLAUNCH(k_ccl_init, dim3((rows + CCL_INIT_ROWS - 1) / CCL_INIT_ROWS), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                 count_mode ? cnt : (int *)nullptr, sparse);
     // rows that start on 16-byte boundaries: word-level walks
     const bool words = (w % 16 == 0) && (((size_t)img & 15) == 0);
@@ -566,7 +570,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
         CPE_KLAUNCH(k_ccl_roots4, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L,
                     roots, cnt_sel);
     else if (!(flags & 2))
-        CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + 2047) / 2048), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
+        CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + CCL_FIN_PX - 1) / CCL_FIN_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
                     holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1, cnt_sel);
     CPE_CHECK_LAUNCH("ccl_run");
     return CPE_OK;

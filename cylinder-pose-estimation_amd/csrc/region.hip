@@ -854,7 +854,7 @@ __device__ __forceinline__ SwRect sw_rect(const FrameState *st, size_t f)
 // ---- pixels of the rectangle sorted by the step at which they join: bucket b is new for the dark set at threshold
 // slot b and for the bright set at slot b - 1, so every later kernel of the sweep runs over a dense list
 __device__ __forceinline__ int sw_level(int v) { return v <= 50 ? 0 : min(NTHR, (v - 41) / 10); }
-constexpr int BK_CHUNK = 4096;    // pixels per workgroup of the two bucket passes
+constexpr int BK_CHUNK = 8192;    // pixels per workgroup of the two bucket passes
 
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img, int h, int w, const FrameState *__restrict__ st,
