@@ -162,6 +162,46 @@ __device__ __forceinline__ unsigned long long col_mask64(int x0, int lo, int hi)
     return m & ~((1ull << a) - 1ull);
 }
 
+// labels of a sparse pass: every pixel of the set points at the first pixel of its run inside the word; a run that
+// continues from the word to the left points at that word's last pixel instead (a chain of at most one link per word,
+// parents always smaller: the same forest the row-wise k_ccl_init builds, a few links deeper)
+__global__ __launch_bounds__(256) void k_ccl_init64(const uint8_t *__restrict__ img, int h, int w, int thr, int invert,
+                                                    const FrameState *__restrict__ st, int use_rect, int *__restrict__ L)
+{
+    const int WW = (w + 63) >> 6, strips = (h + CCL_STRIP - 1) / CCL_STRIP;
+    const size_t f = blockIdx.y;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= WW * strips) return;
+    const int sy = gi / WW, j = gi - sy * WW;
+    const Rect r = get_rect(st, f, use_rect, h, w);
+    const int x0 = j * 64;
+    if (r.x1 < r.x0 || x0 > r.x1 || x0 + 63 < r.x0) return;
+    const int ya = max(sy * CCL_STRIP, r.y0), yb = min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1);
+    const size_t N = (size_t)h * w;
+    const uint8_t *im = img + f * N;
+    int *Lf = L + f * N;
+    const unsigned long long cmask = col_mask64(x0, r.x0, r.x1);
+    const bool hasL = x0 - 1 >= r.x0;
+    for (int y = ya; y <= yb; y++) {
+        const uint8_t *row = im + (size_t)y * w;
+        unsigned long long m = pack_row64(row, x0, w, thr, invert) & cmask;
+        if (!m) continue;
+        const int base = y * w + x0;
+        const bool cL = (m & 1ull) && hasL && pred(row, x0 - 1, thr, invert);
+        while (m) {
+            const unsigned long long low = m & (0ull - m), run = m & ~(m + low);
+            const int a = __ffsll((long long)low) - 1, e = a + __popcll(run);
+            const int label = (a == 0 && cL) ? base - 1 : base + a;
+            int b = a;
+            while (b < e) {
+                if ((b & 3) == 0 && b + 4 <= e) { *reinterpret_cast<int4 *>(Lf + base + b) = make_int4(label, label, label, label); b += 4; }
+                else { Lf[base + b] = label; b++; }
+            }
+            m &= ~run;
+        }
+    }
+}
+
 // same unions as k_ccl_merge
 __global__ __launch_bounds__(256) void k_ccl_merge64(const uint8_t *__restrict__ img, int h, int w, int thr,
                                                      int invert, int conn8, const FrameState *__restrict__ st, int use_rect,
@@ -548,11 +588,14 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     const int rows = n * h;
     CPE_LAUNCH_BEGIN();
     if (roots) CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0, cnt_sel);
-    CPE_KLAUNCH(k_ccl_init, dim3((rows + CCL_INIT_ROWS - 1) / CCL_INIT_ROWS), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
-                count_mode ? cnt : (int *)nullptr, sparse);
     // rows that start on 16-byte boundaries: word-level walks
-    const bool words = (w % 16 == 0) && (((size_t)img & 15) == 0);
+    const bool words = (w % 16 == 0) && (((size_t)img & 15) == 0) && (((size_t)L & 15) == 0);
     const dim3 gwords((unsigned)((((w + 63) / 64) * ((h + CCL_STRIP - 1) / CCL_STRIP) + 255) / 256), n);
+    if (words && sparse == 1 && !count_mode)
+        CPE_KLAUNCH(k_ccl_init64, gwords, dim3(256), 0, s, img, h, w, thr, invert, (const FrameState *)st, use_rect, L);
+    else
+        CPE_KLAUNCH(k_ccl_init, dim3((rows + CCL_INIT_ROWS - 1) / CCL_INIT_ROWS), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
+                    count_mode ? cnt : (int *)nullptr, sparse);
     if (words)
         CPE_KLAUNCH(k_ccl_merge64, gwords, dim3(256), 0, s, img, h, w, thr, invert, conn8, (const FrameState *)st, use_rect, L);
     else
