@@ -11,6 +11,9 @@
 //   touch  : (hole search only) components that reach the border of the working rectangle are flagged
 //   finish : flatten + per-component pixel counts (aggregated per wavefront before the atomic) + root list
 //            + bounding box of the set, all in one read of the label plane
+// When rows start on 16-byte boundaries, init (sparse passes), merge and the roots-only list have word-level forms
+// (k_ccl_init64 / k_ccl_merge64 / k_ccl_roots64): 64 pixels per thread and row as one bit mask, the label plane is
+// touched only where a run starts or two runs start to overlap.
 // A pass can be restricted to a per-frame rectangle (FrameState::crect).  The blob detector uses this:
 // every hole of the binarisation at threshold t lies inside the bounding box of the bright pixels at t,
 // which lies inside the box at t-10; a dark pixel on the box border is 4-connected to the outside, so
