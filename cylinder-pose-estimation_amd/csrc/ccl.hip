@@ -523,6 +523,42 @@ __global__ __launch_bounds__(256) void k_bitplanes(const uint8_t *__restrict__ i
     }
 }
 
+// the same planes when rows start on 16-byte boundaries: a thread loads 64 pixels once (4 x 16 bytes) and makes their word of
+// every plane with SWAR compares -- no ballots, 16 times fewer load instructions
+__global__ __launch_bounds__(256) void k_bitplanes64(const uint8_t *__restrict__ img, int rows_total, int h, int w, int thr0, int step,
+                                                     int nplanes, uint32_t *__restrict__ planes)
+{
+    const int chunks = (w + 63) >> 6;
+    const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= (long long)rows_total * chunks) return;
+    const int row = (int)(gi / chunks), j = (int)(gi - (long long)row * chunks);
+    const int f = row / h, y = row - f * h;
+    const int ws = bit_row_words(w);
+    const size_t plane_words = (size_t)h * ws;
+    uint32_t *out = planes + (size_t)f * nplanes * plane_words + (size_t)y * ws;
+    const uint8_t *p = img + (size_t)row * w + j * 64;
+    unsigned long long v[8];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (j * 64 + 16 * c < w) q = *reinterpret_cast<const uint4 *>(p + 16 * c);   // w % 16 == 0: all 16 inside
+        v[2 * c] = q.x | ((unsigned long long)q.y << 32);
+        v[2 * c + 1] = q.z | ((unsigned long long)q.w << 32);
+    }
+    // pixels past the end of the row were loaded as 0 and every threshold is >= 0: their bits stay clear
+    for (int t = 0; t < nplanes; t++) {
+        const int thr = thr0 + t * step;
+        unsigned long long bits = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) bits |= (unsigned long long)pack8_gt(v[c], thr, 0) << (8 * c);
+        uint32_t *o = out + (size_t)t * plane_words;
+        o[1 + 2 * j] = (uint32_t)bits;
+        o[2 + 2 * j] = (uint32_t)(bits >> 32);
+        if (j == 0) o[0] = 0;
+        if (j == chunks - 1) for (int k = 1 + 2 * chunks; k < ws; k++) o[k] = 0;
+    }
+}
+
 // single plane (mask != 0 / image > thr): one thread per 8 pixels = one byte of the plane (pixel x is bit (x + 32) of its
 // row, so byte 4 + x / 8 holds pixels 8 (x / 8) .. + 7), 64 consecutive bytes per wavefront
 __global__ __launch_bounds__(256) void k_bitplane1(const uint8_t *__restrict__ img, int rows_total, int w, int thr,
@@ -560,6 +596,12 @@ int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step,
         const long long bytes = (long long)n * h * bit_row_words(w) * 4;
         CPE_KLAUNCH(k_bitplane1, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, s, img, n * h, w, thr0, planes);
         CPE_CHECK_LAUNCH("k_bitplane1");
+        return CPE_OK;
+    }
+    if (w % 16 == 0 && (((size_t)img) & 15) == 0 && thr0 >= 0 && step >= 0 && thr0 + (nplanes - 1) * step <= 255) {
+        const long long words = (long long)n * h * ((w + 63) >> 6);
+        CPE_KLAUNCH(k_bitplanes64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, img, n * h, h, w, thr0, step, nplanes, planes);
+        CPE_CHECK_LAUNCH("k_bitplanes64");
         return CPE_OK;
     }
     const long long waves = (long long)n * h * ((((w + 63) >> 6) + 7) >> 3);
