@@ -441,6 +441,35 @@ __global__ __launch_bounds__(256) void k_blur_fused(const uint8_t *__restrict__ 
     if (tid == 0) s_max = 0;
     __syncthreads();
     const uint8_t *im = src + f * N;
+    if (MODE == BLUR_SPOT) {
+        // quick look first: the tile and a 12-pixel apron (a superset of the 9 the blur reads, starting on a dword) hold no
+        // pixel > 240 -> the tile is 0.  Dword loads, 16-byte stores; tiles near the frame border take the general path.
+        const int ax0 = gx0 - 12, ay0 = gy0 - R;
+        constexpr int QW = (BT_X + 24) / 4;
+        if (ax0 >= 0 && ax0 + 4 * QW <= w && ay0 >= 0 && ay0 + IH <= h && gy0 + BT_Y <= h && (w & 15) == 0 &&
+            ((((size_t)im) | ((size_t)dst)) & 15) == 0) {
+            uint32_t any = 0;
+            for (int i = tid; i < IH * QW; i += 256) {
+                const int ry = i / QW, q = i - ry * QW;
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(im + (size_t)(ay0 + ry) * w + ax0 + 4 * q);
+                // a byte > 240 <=> (byte + 15) carries into bit 8 of its own 9-bit field: test the two byte pairs apart
+                const uint32_t lo = (v & 0x00FF00FFu) + 0x000F000Fu, hi = ((v >> 8) & 0x00FF00FFu) + 0x000F000Fu;
+                any |= (lo | hi) & 0x01000100u;
+            }
+            if (__ballot(any != 0) != 0 && (tid & 63) == 0) atomicMax(&s_max, 255);
+            __syncthreads();
+            if (s_max == 0) {
+                for (int i = tid; i < BT_Y * (BT_X / 16); i += 256) {
+                    const int ry = i / (BT_X / 16), q = i - ry * (BT_X / 16);
+                    *reinterpret_cast<uint4 *>(dst + f * N + (size_t)(gy0 + ry) * w + gx0 + 16 * q) = make_uint4(0, 0, 0, 0);
+                }
+                return;
+            }
+            __syncthreads();
+            if (tid == 0) s_max = 0;
+            __syncthreads();
+        }
+    }
     int mx = 0;
     for (int i = tid; i < IH * IW; i += 256) {
         int ry = i / IW, rx = i - ry * IW;
