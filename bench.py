@@ -177,10 +177,13 @@ def main():
         os.environ['CPE_SERIAL'] = '1'
         cpe_amd.lib.profile(True)
         c = min(args.chunk, F)
-        pipe.run_chunk(left[:c], right[:c])
-        torch.cuda.synchronize()
-        rep = cpe_amd.lib.profile_report()
+        reps = []
+        for _ in range(2):   # twice, per-kernel minimum: an event pair also spans any host stall between record and launch
+            pipe.run_chunk(left[:c], right[:c])
+            torch.cuda.synchronize()
+            reps.append({r[0]: r for r in cpe_amd.lib.profile_report()})   # (the report clears the timers)
         cpe_amd.lib.profile(False)
+        rep = sorted(((k, v[1], min(v[2], reps[1].get(k, v)[2])) for k, v in reps[0].items()), key=lambda r: -r[2])
         os.environ.pop('CPE_SERIAL', None)
         tot = sum(r[2] for r in rep)
         name, calls, ms = rep[0]
