@@ -38,8 +38,7 @@ ALGO_BYTES_PER_PX = {
     'k_open20_joints': 4.0,     # u8 mask in, three u8 masks out
     'k_ccl_init64': 1.0, 'k_ccl_merge64': 1.0, 'k_ccl_roots64': 1.0,   # u8 image in; labels touched only at run starts
     'k_bitplanes': 1.0 + 17.0 / 8, 'k_bitplanes64': 1.0 + 17.0 / 8, 'k_bk_pass': 1.0,
-    'k_morph_rect': 2.0,        # u8 in, u8 out
-    'k_blur_h': 3.0, 'k_blur_v': 3.0, 'k_clahe_apply': 2.0, 'k_and2': 3.0, 'k_and3': 4.0, 'k_or_and': 4.0,
+    'k_clahe_apply': 2.0, 'k_or_and': 4.0, 'k_blur_fused': 2.0,
 }
 
 

@@ -17,33 +17,6 @@ int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t
 
 namespace {
 
-// ---- rectangular erode / dilate (anchor kw/2, kh/2; same offsets for both; border never wins) -------------
-__global__ __launch_bounds__(256) void k_morph_rect(const uint8_t *__restrict__ src, size_t total, int h, int w, int kw,
-                                                    int kh, int dilate, uint8_t *__restrict__ dst)
-{
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total) return;
-    const size_t N = (size_t)h * w;
-    const size_t f = gi / N;
-    const int i = (int)(gi - f * N);
-    const int y = i / w, x = i - y * w;
-    const uint8_t *im = src + f * N;
-    const int ax = kw / 2, ay = kh / 2;
-    bool res = !dilate;
-    for (int ky = 0; ky < kh; ky++) {
-        int yy = y + ky - ay;
-        if (yy < 0 || yy >= h) continue;
-        for (int kx = 0; kx < kw; kx++) {
-            int xx = x + kx - ax;
-            if (xx < 0 || xx >= w) continue;
-            bool v = im[(size_t)yy * w + xx] != 0;
-            if (dilate) res = res || v;
-            else res = res && v;
-        }
-    }
-    dst[gi] = res ? 255 : 0;
-}
-
 // a-2 in one kernel: binary -> open(20x1) -> hmask, open(1x20) -> vmask, joints = hmask & vmask.
 // Erosion and dilation both take the in-image pixels of the window [p-10, p+9] (anchor 10 of a 20-tap line; the border
 // never erodes and never dilates).  The kernel works on one-bit rows: a workgroup packs a band of R + 40 rows (all
@@ -201,16 +174,6 @@ __global__ __launch_bounds__(256) void k_open20_joints(const uint8_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_and2(const uint8_t *a, const uint8_t *b, size_t total, uint8_t *dst)
-{
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi < total) dst[gi] = (a[gi] && b[gi]) ? 255 : 0;
-}
-__global__ __launch_bounds__(256) void k_and3(const uint8_t *a, const uint8_t *b, const uint8_t *c, size_t total, uint8_t *dst)
-{
-    size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi < total) dst[gi] = (a[gi] & b[gi]) & c[gi];
-}
 // dst = ((a | b) != 0 ? 255 : 0) & c with c = mask_contour, which is zero outside the region rectangle: rows outside it are
 // written as zeros without reading anything.  grid = (ceil(N / 16384), n), 16 bytes per thread and step when rows allow.
 __global__ __launch_bounds__(256) void k_or_and(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
