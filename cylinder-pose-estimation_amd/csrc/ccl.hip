@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
             if (noflatten) {
                 root = (v == i) ? i : -1;   // only the component list is wanted: a root is a root, flattened or not
             } else if (v >= 0) {
-                root = uf_find_c(L + f * N, v);
+                // read-only walk: the pointer jumping of uf_find_c re-points nodes at *an* ancestor, and such a store from
+                // another thread's walk through this pixel may land after the store below and leave it one hop short
+                root = uf_find(L + f * N, v);
                 L[gi] = root;
             }
         }

@@ -10,7 +10,7 @@ constexpr int MAXSWL = 32768;     // components per threshold of the blob sweep 
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
 constexpr int MAXB = 4096;       // blobs per threshold
 constexpr int MAXG = 2048;       // blob groups (key-point candidates)
-constexpr int GCAP = 20;         // centres per group
+constexpr int GCAP = 32;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = 64;         // grid lines per direction
 constexpr int MAXLP = 64;        // points per grid line

@@ -67,6 +67,22 @@ def test_detect_small_frames_stage_by_stage(cpe, orc, gpu, h, w, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('seed', [20, 21, 22, 23, 24, 25])
+def test_detect_seed_sweep_with_degraded_frames(cpe, orc, gpu, seed):
+    """other scenes, dimmer exposure, extra sensor noise, a dead band: whatever the reference would make of the frame
+    (points or one of its failure statuses), the GPU path makes the same of it"""
+    h, w = ((480, 640), (600, 800), (512, 768))[seed % 3]
+    f = _frames(h, w, 1, seed).numpy().astype(np.int32)
+    rng = np.random.default_rng(seed)
+    f[0] = f[0] * (0.7 + 0.05 * (seed % 5))                                  # dimmer exposure
+    f[1] = f[1] + rng.integers(-6, 7, size=f[1].shape)                        # extra noise
+    if seed % 2:
+        f[1][:, w // 2 - 3:w // 2 + 3] = 0                                    # a dead band through the grid
+    frames = torch.from_numpy(np.clip(f, 0, 255).astype(np.uint8))
+    _compare(cpe, orc, gpu, frames, check_planes=True, allow_overflow=False)
+
+
+@pytest.mark.gpu
 def test_detect_full_size(cpe, orc, gpu):
     from cpe_amd import synth
     b = synth.render_batch(2, 1200, 1920, seed=11, device='cuda', with_gt=False)
