@@ -5,11 +5,12 @@
 namespace cpe {
 
 // ---------------------------------------------------------------- per-image state kept in the workspace
-constexpr int MAXROOTS = 65536;   // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
-constexpr int MAXSWL = 32768;     // components per threshold of the blob sweep (dark away from the border / bright)
+constexpr int MAXROOTS = 131072;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
+constexpr int MAXSWL = 131072;    // components per threshold of the blob sweep (dark away from the border / bright; a noisy
+                                  // 720x1280 frame reaches 58k bright specks at the low thresholds)
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
-constexpr int MAXB = 4096;       // blobs per threshold
-constexpr int MAXG = 2048;       // blob groups (key-point candidates)
+constexpr int MAXB = 8192;       // blobs per threshold
+constexpr int MAXG = 4096;       // blob groups (key-point candidates; their middle centres sit in k_blob_merge's LDS: 96 KB)
 constexpr int GCAP = 32;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = 64;         // grid lines per direction

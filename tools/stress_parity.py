@@ -1,0 +1,84 @@
+"""Differential stress run: randomly degraded synthetic frames through the GPU path and the CPU oracle.
+    python tools/stress_parity.py [cases] [first seed]
+Every frame must come out the same (status, centre, points, ids); a capacity overflow (status 6, build defined) is
+reported separately.  Exit code 1 if any frame differs."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import cpe_amd
+import oracle
+from cpe_amd import api, synth
+from oracle import stages as S
+
+SIZES = [(480, 640), (600, 800), (512, 768), (483, 650), (602, 801), (720, 1280)]
+
+
+def degrade(img, rng):
+    f = img.astype(np.float64)
+    h, w = f.shape
+    what = []
+    if rng.random() < 0.6:
+        s = rng.uniform(0.45, 1.0); f *= s; what.append(f'exposure {s:.2f}')
+    if rng.random() < 0.5:
+        a = int(rng.integers(1, 12)); f += rng.integers(-a, a + 1, size=f.shape); what.append(f'noise {a}')
+    if rng.random() < 0.3:
+        x = int(rng.integers(w // 4, 3 * w // 4)); k = int(rng.integers(2, 9)); f[:, x:x + k] = 0; what.append('v band')
+    if rng.random() < 0.3:
+        y = int(rng.integers(h // 4, 3 * h // 4)); k = int(rng.integers(2, 9)); f[y:y + k, :] = 0; what.append('h band')
+    for _ in range(int(rng.integers(0, 4))):
+        y, x = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 40))
+        hh, ww = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        v = 255 if rng.random() < 0.4 else int(rng.integers(0, 60))
+        f[y:y + hh, x:x + ww] = v; what.append(f'box {v}')
+    if rng.random() < 0.2:
+        f += np.linspace(0, rng.uniform(20, 80), w)[None, :]; what.append('gradient')
+    return np.clip(f, 0, 255).astype(np.uint8), what
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    dev = torch.device('cuda:0')
+    cpe_amd.lib.load(); oracle.build()
+    bad = ovf = okf = 0
+    t0 = time.time()
+    for c in range(cases):
+        seed = seed0 + c
+        rng = np.random.default_rng(seed)
+        h, w = SIZES[seed % len(SIZES)]
+        b = synth.render_batch(1, h, w, seed=seed, with_gt=False)
+        frames, notes = [], []
+        for img in (b['left'][0].numpy(), b['right'][0].numpy()):
+            d, what = degrade(img, rng); frames.append(d); notes.append(what)
+        frames = np.stack(frames)
+        det = api.detect_grid_batch(torch.from_numpy(frames).to(dev))
+        torch.cuda.synchronize()
+        state = det['ws'].state()
+        for i in range(2):
+            ref = S.detect_grid(frames[i])
+            st = int(det['status'][i])
+            if st == 6:
+                ovf += 1
+                print(f'seed {seed} frame {i} {h}x{w}: capacity overflow bits {state[i]["overflow"]} (oracle status {ref["status"]}) {notes[i]}')
+                continue
+            same = st == ref['status']
+            if same and st == 0:
+                m = int(det['n'][i])
+                same = (m == len(ref['xy']) and np.array_equal(det['xy'][i, :m].cpu().numpy(), ref['xy'])
+                        and np.array_equal(det['id'][i, :m].cpu().numpy(), ref['id'])
+                        and np.array_equal(det['center'][i].cpu().numpy(), ref['center']))
+                okf += 1
+            if not same:
+                bad += 1
+                print(f'seed {seed} frame {i} {h}x{w}: MISMATCH gpu status {st} oracle {ref["status"]} {notes[i]}')
+    print(f'{2 * cases} frames in {time.time() - t0:.0f} s: {bad} mismatches, {ovf} capacity overflows, {okf} with points')
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
