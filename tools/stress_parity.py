@@ -1,5 +1,5 @@
 """Differential stress run: randomly degraded synthetic frames through the GPU path and the CPU oracle.
-    python tools/stress_parity.py [cases] [first seed]
+    python tools/stress_parity.py [cases] [first seed] [cylinder|plane]
 Every frame must come out the same (status, centre, points, ids); a capacity overflow (status 6, build defined) is
 reported separately.  Exit code 1 if any frame differs."""
 import os
@@ -43,6 +43,8 @@ def degrade(img, rng):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    target = sys.argv[3] if len(sys.argv) > 3 else 'cylinder'
+    ref_fn = S.detect_grid_plane if target == 'plane' else S.detect_grid
     dev = torch.device('cuda:0')
     cpe_amd.lib.load(); oracle.build()
     bad = ovf = okf = 0
@@ -56,11 +58,11 @@ def main():
         for img in (b['left'][0].numpy(), b['right'][0].numpy()):
             d, what = degrade(img, rng); frames.append(d); notes.append(what)
         frames = np.stack(frames)
-        det = api.detect_grid_batch(torch.from_numpy(frames).to(dev))
+        det = api.detect_grid_batch(torch.from_numpy(frames).to(dev), target=target)
         torch.cuda.synchronize()
         state = det['ws'].state()
         for i in range(2):
-            ref = S.detect_grid(frames[i])
+            ref = ref_fn(frames[i])
             st = int(det['status'][i])
             if st == 6:
                 ovf += 1
