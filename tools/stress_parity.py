@@ -1,5 +1,7 @@
 """Differential stress run: randomly degraded synthetic frames through the GPU path and the CPU oracle.
     python tools/stress_parity.py [cases] [first seed] [cylinder|plane]
+For the cylinder script the stereo pair also goes through chooseIdx + triangulate + the Nelder-Mead fit on both sides
+(cylinder parameters compared for equality).
 Every frame must come out the same (status, centre, points, ids); a capacity overflow (status 6, build defined) is
 reported separately.  Exit code 1 if any frame differs."""
 import os
@@ -12,7 +14,7 @@ import torch
 
 import cpe_amd
 import oracle
-from cpe_amd import api, synth
+from cpe_amd import api, fit, synth
 from oracle import stages as S
 
 SIZES = [(480, 640), (600, 800), (512, 768), (483, 650), (602, 801), (720, 1280)]
@@ -47,7 +49,7 @@ def main():
     ref_fn = S.detect_grid_plane if target == 'plane' else S.detect_grid
     dev = torch.device('cuda:0')
     cpe_amd.lib.load(); oracle.build()
-    bad = ovf = okf = 0
+    bad = ovf = okf = fits = 0
     t0 = time.time()
     for c in range(cases):
         seed = seed0 + c
@@ -61,8 +63,9 @@ def main():
         det = api.detect_grid_batch(torch.from_numpy(frames).to(dev), target=target)
         torch.cuda.synchronize()
         state = det['ws'].state()
+        refs = []
         for i in range(2):
-            ref = ref_fn(frames[i])
+            ref = ref_fn(frames[i]); refs.append(ref)
             st = int(det['status'][i])
             if st == 6:
                 ovf += 1
@@ -78,6 +81,16 @@ def main():
             if not same:
                 bad += 1
                 print(f'seed {seed} frame {i} {h}x{w}: MISMATCH gpu status {st} oracle {ref["status"]} {notes[i]}')
+        if target == 'cylinder' and all(r['status'] == 0 for r in refs) and int(det['status'][0]) == 0 and int(det['status'][1]) == 0:
+            g1 = fit.GridTables(det['xy'][:1], det['id'][:1], det['n'][:1]); g2 = fit.GridTables(det['xy'][1:], det['id'][1:], det['n'][1:])
+            out = fit.fit_single_cylinder_batch(g1, g2, b['K1'], b['K2'], b['T21'], b['radius'])
+            want = oracle.fit_single_cylinder(np.concatenate([refs[0]['xy'], refs[0]['id']], 1), np.concatenate([refs[1]['xy'], refs[1]['id']], 1),
+                                              b['K1'], b['K2'], b['T21'], b['radius'])
+            fits += 1
+            if not np.array_equal(out['cyl'][0].cpu().numpy(), want['cyl']):
+                bad += 1
+                print(f'seed {seed}: FIT MISMATCH', out['cyl'][0].cpu().numpy().tolist(), want['cyl'].tolist())
+    print(f'{fits} stereo pairs fitted on both sides')
     print(f'{2 * cases} frames in {time.time() - t0:.0f} s: {bad} mismatches, {ovf} capacity overflows, {okf} with points')
     sys.exit(1 if bad else 0)
 
