@@ -10,7 +10,8 @@ constexpr int MAXSWL = 131072;    // components per threshold of the blob sweep 
                                   // 720x1280 frame reaches 58k bright specks at the low thresholds)
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
 constexpr int MAXB = 8192;       // blobs per threshold
-constexpr int MAXG = 4096;       // blob groups (key-point candidates; their middle centres sit in k_blob_merge's LDS: 96 KB)
+constexpr int MAXG = 16384;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
+constexpr int MAXG_LDS = 4096;   // ... whose middle centres sit in k_blob_merge's LDS (96 KB); the rest are read from HBM
 constexpr int GCAP = 32;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = 64;         // grid lines per direction
@@ -65,6 +66,7 @@ struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
 struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
     int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
+    double *gmid;              // middle centres (x, y, r) of the blob groups beyond MAXG_LDS
     int *hpar; uint8_t *htime;   // merge history of the bright forest: (absorbing root, step) per absorbed entry
     uint32_t *pool;   // border points of the hole traces (chunked)
     unsigned short *blob_ch;   // first 16 chunk ids of every blob's border

@@ -587,10 +587,10 @@ __device__ __forceinline__ int wave_min_int(int v)
 constexpr int MG_NT = 1024;   // threads of k_blob_merge (16 wavefronts: the group search and the pair tests are split over them)
 __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
                                                     const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
-                                                    Group *__restrict__ groups, int always_replay)
+                                                    Group *__restrict__ groups, int always_replay, double *__restrict__ gmid_all)
 {
     // location + radius of each group's middle centre (what the tests read)
-    __shared__ double sX[MAXG], sY[MAXG], sR[MAXG];
+    __shared__ double sX[MAXG_LDS], sY[MAXG_LDS], sR[MAXG_LDS];   // groups >= MAXG_LDS: gmid (HBM, this workgroup only)
     __shared__ double bX[64], bY[64], bR[64];
     __shared__ double pl[GCAP * 3][64];   // centre lists of the groups the batch touches: [element][slot], lanes = slots
     __shared__ double cX[64], cY[64], cR[64];   // middle centre each blob's group gets if the blob is inserted
@@ -601,6 +601,19 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     FrameState &S = st[f];
     int *ord = order + (size_t)f * MAXB;
     Group *G = groups + (size_t)f * MAXG;
+    double *gm = gmid_all + (size_t)f * (MAXG - MAXG_LDS) * 3 - (size_t)MAXG_LDS * 3;   // gm[3 j ..] for j >= MAXG_LDS
+    auto mid_joins = [&](int j, double cx, double cy, double cr) {
+        if (j < MAXG_LDS) return blob_joins(sX[j], sY[j], sR[j], cx, cy, cr);
+        // written by other wavefronts of this workgroup between barriers: read past the vector L1
+        const double gx = __hip_atomic_load(gm + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double gy = __hip_atomic_load(gm + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double gr = __hip_atomic_load(gm + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return blob_joins(gx, gy, gr, cx, cy, cr);
+    };
+    auto mid_set = [&](int j, double x, double y, double r) {
+        if (j < MAXG_LDS) { sX[j] = x; sY[j] = y; sR[j] = r; }
+        else { gm[3 * j] = x; gm[3 * j + 1] = y; gm[3 * j + 2] = r; }
+    };
     int ng = 0;
     for (int thr = 0; thr < NTHR; thr++) {
         const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + thr], MAXB);
@@ -627,7 +640,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
                 int first = act ? INT_MAX : -1;
                 for (int j = jlo; j < jhi; j++) {
-                    if (first == INT_MAX && blob_joins(sX[j], sY[j], sR[j], cx, cy, cr)) first = j;
+                    if (first == INT_MAX && mid_joins(j, cx, cy, cr)) first = j;
                     if ((j & 15) == 15 && !__ballot(first == INT_MAX)) break;
                 }
                 if (act && first != INT_MAX) atomicMin(&s_jm[lane], first);
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                         }
                         pl[3 * pos][lane] = cx; pl[3 * pos + 1][lane] = cy; pl[3 * pos + 2][lane] = cr;
                         pn[lane] = gn + 1; pd[lane] = 1;
-                        sX[jm] = nx; sY[jm] = ny; sR[jm] = nr;
+                        mid_set(jm, nx, ny, nr);
                     }
                     if (mine && full) set_overflow(S, OVF_GROUPS);
                     const bool fresh = mine && jm == INT_MAX;
@@ -714,7 +727,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                             Group &g = G[gi];
                             g.n = 1;
                             g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
-                            sX[gi] = cx; sY[gi] = cy; sR[gi] = cr;
+                            mid_set(gi, cx, cy, cr);
                         } else set_overflow(S, OVF_GROUPS);
                     }
                     ng = min(ng + __popcll(fb), MAXG);
@@ -733,11 +746,11 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                     if (changed) {
                         int jmin = INT_MAX;
                         for (int j = lane; j < ng0; j += 64)
-                            if (blob_joins(sX[j], sY[j], sR[j], cx, cy, cr)) jmin = min(jmin, j);
+                            if (mid_joins(j, cx, cy, cr)) jmin = min(jmin, j);
                         jm = wave_min_int(jmin);
                     } else {
                         int cand = INT_MAX;
-                        if (mj >= 0 && mj < jm && blob_joins(sX[mj], sY[mj], sR[mj], cx, cy, cr)) cand = mj;
+                        if (mj >= 0 && mj < jm && mid_joins(mj, cx, cy, cr)) cand = mj;
                         jm = min(jm, wave_min_int(cand));
                     }
                     if (jm != INT_MAX) {
@@ -768,7 +781,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                                 if (lane >= pos && lane < gn) { g.c[lane + 1][0] = ex; g.c[lane + 1][1] = ey; g.c[lane + 1][2] = er; }
                                 if (lane == 0) { g.c[pos][0] = cx; g.c[pos][1] = cy; g.c[pos][2] = cr; g.n = gn + 1; }
                             }
-                            if (lane == 0) { sX[jm] = sx; sY[jm] = sy; sR[jm] = sr; }
+                            if (lane == 0) mid_set(jm, sx, sy, sr);
                             if (__ballot(mj == jm) == 0ull) {   // first change of this group in the batch
                                 if (lane == 0) s_mod[nm] = jm;
                                 nm++;
@@ -779,7 +792,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                             Group &g = G[ng];
                             g.n = 1;
                             g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
-                            sX[ng] = cx; sY[ng] = cy; sR[ng] = cr;
+                            mid_set(ng, cx, cy, cr);
                         }
                         ng++;
                     } else if (lane == 0) set_overflow(S, OVF_GROUPS);
@@ -1507,7 +1520,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
         const char *e = getenv("CPE_MERGE_REPLAY");
         CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(MG_NT), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups,
-                    (e && e[0] == '1') ? 1 : 0);
+                    (e && e[0] == '1') ? 1 : 0, B.gmid);
     }
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
