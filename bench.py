@@ -204,6 +204,12 @@ def main():
                     algorithmic_bytes_per_launch=algo, achieved=algo / avg_s / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
                     frac=(algo / avg_s) / HBM_PEAK, traffic=pmc_traffic(short, 2 * c),
                     top5=[dict(kernel=r[0].split('::')[-1], calls=r[1], ms=round(r[2], 3)) for r in rep[:5]])
+        if short == 'k_preprocess':
+            # what actually bounds this kernel: ~314 f64 operations per pixel, multiplies and adds kept
+            # apart for bit parity with scipy, so the ceiling is half the 78.6 TFLOP/s FMA figure of MI355X_MICROARCH.md
+            flops = 314.0 * px_per_launch
+            roof['f64_valu'] = dict(ops_per_px=314, achieved=flops / avg_s / 1e12, peak=78.6 / 2, unit='Tflop/s (separate f64 add / mul)',
+                                    frac=flops / avg_s / 1e12 / (78.6 / 2))
 
     if rank == 0:
         n_pts, iters, fit_st, dl, dr = pipeline.unpack_counters(allrec[:, 15])

@@ -1,5 +1,5 @@
 """Differential stress run: randomly degraded synthetic frames through the GPU path and the CPU oracle.
-    python tools/stress_parity.py [cases] [first seed] [cylinder|plane]
+    python tools/stress_parity.py [cases] [first seed] [cylinder|plane] [full]     (full: 1200x1920 frames only)
 For the cylinder script the stereo pair also goes through chooseIdx + triangulate + the Nelder-Mead fit on both sides
 (cylinder parameters compared for equality).
 Every frame must come out the same (status, centre, points, ids); a capacity overflow (status 6, build defined) is
@@ -54,7 +54,7 @@ def main():
     for c in range(cases):
         seed = seed0 + c
         rng = np.random.default_rng(seed)
-        h, w = SIZES[seed % len(SIZES)]
+        h, w = (1200, 1920) if 'full' in sys.argv[4:] else SIZES[seed % len(SIZES)]
         b = synth.render_batch(1, h, w, seed=seed, with_gt=False)
         frames, notes = [], []
         for img in (b['left'][0].numpy(), b['right'][0].numpy()):
