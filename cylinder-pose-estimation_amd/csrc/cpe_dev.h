@@ -6,8 +6,14 @@ namespace cpe {
 
 // ---------------------------------------------------------------- per-image state kept in the workspace
 constexpr int MAXROOTS = 131072;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
-constexpr int MAXSWL = 131072;    // components per threshold of the blob sweep (dark away from the border / bright; a noisy
-                                  // 720x1280 frame reaches 58k bright specks at the low thresholds)
+// components per threshold of the blob sweep (dark away from the border / bright): grows with the frame, one list entry
+// per 8 pixels (CLAHE turns sensor noise into specks: a 1920x1200 frame with +-9 DN of noise has > 131072 per threshold)
+__host__ __device__ inline int sweep_cap(int h, int w)
+{
+    long long v = (long long)h * w / 8;
+    v = v < 32768 ? 32768 : (v > (1 << 20) ? (1 << 20) : v);
+    return (int)((v + 255) / 256 * 256);
+}
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
 constexpr int MAXB = 8192;       // blobs per threshold
 constexpr int MAXG = 16384;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)

@@ -273,7 +273,7 @@ __device__ __forceinline__ void blob_trace_one(int f, int slot, int k, int h, in
                                                unsigned short *__restrict__ blob_ch_all, int maxch, int maxdf,
                                                unsigned long long *s_win, unsigned short *s_ids)
 {
-    const int2 e = lists[((size_t)f * NTHR + slot) * MAXSWL + k];
+    const int2 e = lists[((size_t)f * NTHR + slot) * sweep_cap(h, w) + k];
     const int root = e.x;
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     __shared__ unsigned short s_ids[CH_DIRECT * 64];
     const int f = blockIdx.y, slot = blockIdx.z;
     int *S = sw + (size_t)f * SW_STRIDE;
-    const int cnt = min(S[cnt_base + slot], MAXSWL);
+    const int cnt = min(S[cnt_base + slot], sweep_cap(h, w));
     for (int k = blockIdx.x * 64 + threadIdx.x; k < cnt; k += gridDim.x * 64)
         blob_trace_one<is_hole>(f, slot, k, h, w, lists, st, S, blobs_all, blob_d_all, dists_all, bits, pool_all, blob_ch_all, maxch, maxdf,
                                 s_win, s_ids);
@@ -835,18 +835,19 @@ __global__ __launch_bounds__(ENC_NT) void k_enclosed_all(const int2 *__restrict_
     const int *hp = hpar + f * N;
     const uint8_t *ht = htime + f * N;
     int *ef = encl + f * N;
+    const size_t cap = (size_t)sweep_cap(h, w);
     for (int slot = 0; slot < NTHR; slot++) {
         const int t = NTHR - 1 - slot;                     // bright step of this threshold
-        const int nh = min(S[SW_NH + slot], MAXSWL), nl = min(S[SW_NL + slot], MAXSWL);
+        const int nh = min(S[SW_NH + slot], cap), nl = min(S[SW_NL + slot], cap);
         for (int k = threadIdx.x; k < nh; k += ENC_NT) {
-            const int2 e = hl[(f * NTHR + slot) * MAXSWL + k];
+            const int2 e = hl[(f * NTHR + slot) * cap + k];
             int c = e.x - 1;                               // bright pixel west of the hole
             while ((int)ht[c] <= t) c = hp[c];
             atomicAdd(&ef[c], min(e.y, 5000));
         }
         __syncthreads();
         for (int k = threadIdx.x; k < nl; k += ENC_NT) {
-            int2 &g = bl[(f * NTHR + slot) * MAXSWL + k];
+            int2 &g = bl[(f * NTHR + slot) * cap + k];
             g.y = atomicExch(&ef[g.x], 0);
         }
         __syncthreads();
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(256) void k_sw_touch(const uint8_t *__restrict__ im
     if ((int)img[f * N + p] <= hi) touch[f * N + uf_find(P + f * N, p)] = (uint8_t)epoch;
 }
 
-__device__ __forceinline__ void sw_append(bool want, int value, int *counter, int2 *list, FrameState *S)
+__device__ __forceinline__ void sw_append(bool want, int value, int *counter, int2 *list, FrameState *S, int cap)
 {
     const int lane = threadIdx.x & 63;
     unsigned long long b = __ballot(want);
@@ -1009,7 +1010,7 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
     base = __shfl(base, leader, 64);
     if (want) {
         int k = base + __popcll(b & ((1ull << lane) - 1ull));
-        if (k < MAXSWL) list[k].x = value;
+        if (k < cap) list[k].x = value;
         else set_overflow(*S, OVF_SWEEP);
     }
 }
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
                 active &= ~same;
             }
         } else if (is_root) acc[f * N + i] = 0;
-        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXSWL, &st[f]);
+        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * (size_t)sweep_cap(h, w), &st[f], sweep_cap(h, w));
     }
 }
 
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
             else { hpar[f * N + r] = uf_find_c(Pf, r); htime[f * N + r] = (uint8_t)epoch; }   // absorbed at this step
         }
     }
-    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * MAXSWL, &st[f]);
+    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * (size_t)sweep_cap(h, w), &st[f], sweep_cap(h, w));
     }
 }
 
@@ -1121,14 +1122,15 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
                                                  int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int cnt = min(sw[f * SW_STRIDE + cnt_base + slot], MAXSWL);
+    const size_t cap = (size_t)sweep_cap(h, w);
+    const int cnt = min(sw[f * SW_STRIDE + cnt_base + slot], (int)cap);
     const int lane = threadIdx.x & 63;
     for (int k0 = blockIdx.x * 256; k0 < cnt; k0 += gridDim.x * 256) {
         const int k = k0 + threadIdx.x;
         const bool valid = k < cnt;
         int2 e = make_int2(0, 0);
         if (valid) {
-            int2 &g = lists[(f * NTHR + slot) * MAXSWL + k];
+            int2 &g = lists[(f * NTHR + slot) * cap + k];
             g.y = acc[f * N + g.x];
             e = g;
         }
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
         int base = 0;
         if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
         base = __shfl(base, leader, 64);
-        if (want) trace[(f * NTHR + slot) * MAXSWL + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
+        if (want) trace[(f * NTHR + slot) * cap + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
     }
 }
 
@@ -1439,7 +1441,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(n, 4, MAXSWL / 256), n), gtrace(frame_waves(n * NTHR, 8, MAXSWL / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, MAXSWL / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
+    const int swcap = sweep_cap(h, w);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1448,7 +1451,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_CHECK_LAUNCH("grey-level buckets");
     }
     const int per = 2 * w + 2 * h;
-    const size_t lstride = (size_t)NTHR * MAXSWL * 2;   // ints per frame of a list array
+    const size_t lstride = (size_t)NTHR * swcap * 2;   // ints per frame of a list array
     // the dark sweep and the hole borders run on the helper stream (if any) beside the bright sweep: the two forests
     // only meet in k_enclosed_all
     hipStream_t ds = side ? side->s : s;
@@ -1474,7 +1477,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, k + 1 < NTHR ? k + 1 : 0, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)B.hl + (size_t)(k - 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)B.hl + (size_t)(k - 1) * swcap * 2, lstride, 2, swcap,
                         (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
         }
@@ -1504,7 +1507,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
                     (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
         if (j > 0)
-            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * MAXSWL * 2, lstride, 2, (int)MAXSWL,
+            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * swcap * 2, lstride, 2, swcap,
                         (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, j,
                         B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
