@@ -15,7 +15,7 @@ __host__ __device__ inline int sweep_cap(int h, int w)
     return (int)((v + 255) / 256 * 256);
 }
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
-constexpr int MAXB = 8192;       // blobs per threshold
+constexpr int MAXB = 16384;      // blobs per threshold
 constexpr int MAXG = 16384;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
 constexpr int MAXG_LDS = 4096;   // ... whose middle centres sit in k_blob_merge's LDS (96 KB); the rest are read from HBM
 constexpr int GCAP = 32;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
