@@ -1,5 +1,6 @@
 """Differential stress run: randomly degraded synthetic frames through the GPU path and the CPU oracle.
-    python tools/stress_parity.py [cases] [first seed] [cylinder|plane] [full]     (full: 1200x1920 frames only)
+    python tools/stress_parity.py [cases] [first seed] [cylinder|plane] [full] [subpixel]
+(full: 1200x1920 frames only; subpixel: the optional grey-level line refinement, row f-4, on both sides)
 For the cylinder script the stereo pair also goes through chooseIdx + triangulate + the Nelder-Mead fit on both sides
 (cylinder parameters compared for equality).
 Every frame must come out the same (status, centre, points, ids); a capacity overflow (status 6, build defined) is
@@ -46,7 +47,8 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     target = sys.argv[3] if len(sys.argv) > 3 else 'cylinder'
-    ref_fn = S.detect_grid_plane if target == 'plane' else S.detect_grid
+    subpixel = 'subpixel' in sys.argv[4:]
+    ref_fn = S.detect_grid_plane if target == 'plane' else (lambda g: S.detect_grid(g, subpixel=subpixel))
     dev = torch.device('cuda:0')
     cpe_amd.lib.load(); oracle.build()
     bad = ovf = okf = fits = 0
@@ -60,7 +62,7 @@ def main():
         for img in (b['left'][0].numpy(), b['right'][0].numpy()):
             d, what = degrade(img, rng); frames.append(d); notes.append(what)
         frames = np.stack(frames)
-        det = api.detect_grid_batch(torch.from_numpy(frames).to(dev), target=target)
+        det = api.detect_grid_batch(torch.from_numpy(frames).to(dev), target=target, subpixel=subpixel)
         torch.cuda.synchronize()
         state = det['ws'].state()
         refs = []
