@@ -20,7 +20,7 @@ constexpr int MAXG = 16384;      // blob groups (one per unmatched blob: a noisy
 constexpr int MAXG_LDS = 4096;   // ... whose middle centres sit in k_blob_merge's LDS (96 KB); the rest are read from HBM
 constexpr int GCAP = 32;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
-constexpr int MAXL = 64;         // grid lines per direction
+constexpr int MAXL = 128;        // grid lines per direction (label groups of the joints: noise joints make extra ones)
 constexpr int MAXLP = 64;        // points per grid line
 constexpr int MAXSEG = 2048;     // line fragments per mask in the expansion stage
 

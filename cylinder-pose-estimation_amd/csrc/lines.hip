@@ -351,37 +351,42 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         }
     }
     __syncthreads();
+    static_assert(MAXL == 128, "the grouping below gives every lane of a wavefront two groups");
     if (t < 128) {
         const int sd = t >> 6, lane = t & 63;
-        int ng = 0, my_lab = -2, my_n = 0;   // lane k owns group k (MAXL == 64)
+        int ng = 0, my_lab[2] = {-2, -2}, my_n[2] = {0, 0};   // lane k owns groups k and k + 64
         bool ovf = false;
         for (int i = 0; i < nj; i++) {
             const int lab = s_lab[sd][i];
             if (lab < 0) continue;
-            const unsigned long long mb = __ballot(lane < ng && my_lab == lab);
+            const unsigned long long mb0 = __ballot(lane < ng && my_lab[0] == lab);
+            const unsigned long long mb1 = __ballot(lane + 64 < ng && my_lab[1] == lab);
             int g;
-            if (mb) g = __ffsll((long long)mb) - 1;
+            if (mb0) g = __ffsll((long long)mb0) - 1;
+            else if (mb1) g = 64 + __ffsll((long long)mb1) - 1;
             else {
                 if (ng == MAXL) { ovf = true; continue; }
                 g = ng++;
-                if (lane == g) { my_lab = lab; my_n = 0; }
+                if (lane == (g & 63)) { my_lab[g >> 6] = lab; my_n[g >> 6] = 0; }
             }
-            if (lane == g) {
-                if (my_n < MAXLP) {
-                    W.gpts[sd][g][my_n][0] = (double)J[2 * i];
-                    W.gpts[sd][g][my_n][1] = (double)J[2 * i + 1];
-                    my_n++;
+            if (lane == (g & 63)) {
+                int &cnt = my_n[g >> 6];
+                if (cnt < MAXLP) {
+                    W.gpts[sd][g][cnt][0] = (double)J[2 * i];
+                    W.gpts[sd][g][cnt][1] = (double)J[2 * i + 1];
+                    cnt++;
                 } else ovf = true;
             }
         }
-        if (lane < ng) { W.glabel[sd][lane] = my_lab; W.gn[sd][lane] = my_n; }
+        if (lane < ng) { W.glabel[sd][lane] = my_lab[0]; W.gn[sd][lane] = my_n[0]; }
+        if (lane + 64 < ng) { W.glabel[sd][lane + 64] = my_lab[1]; W.gn[sd][lane + 64] = my_n[1]; }
         if (__ballot(ovf)) s_ovf = 1;
         if (lane == 0) s_ng[sd] = ng;
     }
     __syncthreads();
     // sort_rows: stable by min y (rows AND cols), then create_dummy_rows_cols + fit (degree 2)
-    if (t < 128) {
-        const int sd = t >> 6, g = t & 63;
+    if (t < 2 * MAXL) {
+        const int sd = t / MAXL, g = t % MAXL;
         if (g < s_ng[sd]) {
             const int n = W.gn[sd][g];
             double m = W.gpts[sd][g][0][1];
@@ -490,8 +495,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         const int half = sp_window / 2;
         const uint8_t *gimg = gray + f * N;
         float *sbase = sp_scratch + (size_t)f * 2 * MAXL * 2 * sp_cap;
-        if (t < 128) {
-            const int sd = t >> 6, pos = t & 63;
+        if (t < 2 * MAXL) {
+            const int sd = t / MAXL, pos = t % MAXL;
             int K = 0;
             if (pos < s_n[sd]) {
                 const double *eq = W.eq[sd][s_ord[sd][pos]];
@@ -503,8 +508,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             s_K[t] = K;
         }
         __syncthreads();
-        for (int l = 0; l < 128; l++) {
-            const int sd = l >> 6, pos = l & 63;
+        for (int l = 0; l < 2 * MAXL; l++) {
+            const int sd = l / MAXL, pos = l % MAXL;
             const int K = s_K[l];
             if (K == 0) continue;
             if (K > sp_cap) { if (t == 0) s_ovf = 1; continue; }
@@ -526,10 +531,10 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             if (t == 0) S.status = CPE_ST_SUBPIXEL_RAISED;
             return;
         }
-        if (t < 128) {
+        if (t < 2 * MAXL) {
             const int K = s_K[t];
             if (K >= 3 && K <= sp_cap) {
-                const int sd = t >> 6, pos = t & 63;
+                const int sd = t / MAXL, pos = t % MAXL;
                 double *eq = W.eq[sd][s_ord[sd][pos]];
                 const float *xs = sbase + (size_t)t * 2 * sp_cap, *ys = xs + sp_cap;
                 double c[3];
@@ -556,8 +561,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     }
     __syncthreads();
     // per-line lists in loop order, and the clean_and_relabel keys (mean y for rows, mean x for cols)
-    if (t < 128) {
-        const int sd = t >> 6, pos = t & 63;
+    if (t < 2 * MAXL) {
+        const int sd = t / MAXL, pos = t % MAXL;
         if (pos < s_n[sd]) {
             const int slot = s_ord[sd][pos];
             int k = 0;
