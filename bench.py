@@ -48,8 +48,8 @@ def list_kernel_bytes(short, ws, n_img):
     st = ws.state()
     dark, bright, blobs = sw[:, 8:25].sum(), sw[:, 25:42].sum(), sw[:, 42:59].sum()
     groups = sum(s_['n_groups'] for s_ in st)
-    if short == 'k_blob_merge':      # 32-B blob records in, 776-B group lists read + written once per touching blob
-        return blobs * (32 + 2 * 776)
+    if short == 'k_blob_merge':      # 32-B blob records in, 1544-B group lists read + written once per touching blob
+        return blobs * (32 + 2 * 1544)
     if short == 'k_blob_median':     # ~160 border points of 4 B per blob in, radius out
         return blobs * (160 * 4 + 8)
     if short.startswith('k_blob_trace'):   # a border step reads 3 x 8 B of the bit window, stores a 4-B point

@@ -17,8 +17,8 @@ __host__ __device__ inline int sweep_cap(int h, int w)
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
 constexpr int MAXB = 16384;      // blobs per threshold
 constexpr int MAXG = 16384;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
-constexpr int MAXG_LDS = 4096;   // ... whose middle centres sit in k_blob_merge's LDS (96 KB); the rest are read from HBM
-constexpr int GCAP = 32;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
+constexpr int MAXG_LDS = 2048;   // ... whose middle centres sit in k_blob_merge's LDS (48 KB); the rest are read from HBM
+constexpr int GCAP = 64;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = 128;        // grid lines per direction (label groups of the joints: noise joints make extra ones)
 constexpr int MAXLP = 64;        // points per grid line
