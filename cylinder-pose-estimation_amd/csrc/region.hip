@@ -661,8 +661,9 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
                 const int g = pg[q];
                 if (g >= 0) {
-                    if (e == GCAP * 3) pn[q] = G[g].n;
-                    else pl[e][q] = G[g].c[e / 3][e % 3];
+                    const int gn = G[g].n;             // only the entries in use are fetched
+                    if (e == GCAP * 3) pn[q] = gn;
+                    else if (e < 3 * gn) pl[e][q] = G[g].c[e / 3][e % 3];
                 }
             }
             __syncthreads();
