@@ -108,20 +108,23 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         for (int i = tid; i < BH * SB; i += NT) {
             const int ry = i / SB, u0 = (i - ry * SB) * 8;
             const int y = gy0 - RB + ry;
-            int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // separable (integers: any order is exact): the 12 column sums with weights 1 4 6 4 1 first, then the 8 outputs
+            int col[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int dy = 0; dy < 5; dy++) {
                 const int ky = (dy == 0 || dy == 4) ? 1 : ((dy == 2) ? 6 : 4);
                 const uint32_t *q = a32 + ((ry + dy) * AW + u0) / 4;
                 const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-                int p[12];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    p[k] = (d0 >> (8 * k)) & 255; p[4 + k] = (d1 >> (8 * k)) & 255; p[8 + k] = (d2 >> (8 * k)) & 255;
+                    col[k] += ky * (int)((d0 >> (8 * k)) & 255);
+                    col[4 + k] += ky * (int)((d1 >> (8 * k)) & 255);
+                    col[8 + k] += ky * (int)((d2 >> (8 * k)) & 255);
                 }
-#pragma unroll
-                for (int o = 0; o < 8; o++) acc[o] += ky * (p[o] + 4 * p[o + 1] + 6 * p[o + 2] + 4 * p[o + 3] + p[o + 4]);
             }
+            int acc[8];
+#pragma unroll
+            for (int o = 0; o < 8; o++) acc[o] = col[o] + 4 * col[o + 1] + 6 * col[o + 2] + 4 * col[o + 3] + col[o + 4];
             const bool yin = y >= 0 && y < h;
 #pragma unroll
             for (int o = 0; o < 8; o++) {
