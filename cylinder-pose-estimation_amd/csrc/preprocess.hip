@@ -26,6 +26,9 @@ constexpr int BW = TX + 2 * RB, BH = TY + 2 * RB;   // 106
 constexpr int VW = BW, VH = TY + 2 * RG;            // 106 x 82
 constexpr int GW_ = TX + 2 * RG, GH = TY + 2 * RG;  // 82 x 82
 constexpr int EW = TX + 2 * RE, EH = TY + 2 * RE;   // 78 x 78
+// LDS row strides (in doubles) of b and of the row sums: with lanes = rows, an odd stride spreads a 32-lane group's 8-byte
+// accesses over all 64 banks (stride 78 / 64 cost the row-sum phases 2x on reads and 8x on writes)
+constexpr int EWP = EW + 1, RSP = TX + 1;
 
 __constant__ double c_gw[13] = {
     0x1.105a329f98197p-3, 0x1.01a25f86eb137p-3, 0x1.b42a57d56c0bep-4,
@@ -41,7 +44,7 @@ struct Smem {
     double buf2[GH * GW_]; // G, later row sums
 };
 static_assert(sizeof(Smem) <= 160 * 1024, "LDS budget");
-static_assert(EH * EW <= VH * VW && EH * TX <= GH * GW_, "buffer reuse");
+static_assert(EH * EWP <= VH * VW && EH * RSP <= GH * GW_, "buffer reuse");
 
 // np.gradient of G (LDS tile, global coords) -- one-sided at the image border
 struct GView {
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
             double t5 = t2 + t4;
             double t7 = sqrt(t5) / 2.0;
             double t9 = (m00 + m11) / 2.0;
-            bb[i] = t9 - t7;
+            bb[ry * EWP + rx] = t9 - t7;
         }
     }
     __syncthreads();
@@ -259,11 +262,11 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
     double mean[KG];
     auto row_sums = [&](bool squared) {
         if (tid < GF * EH) {
-            const int ry = tid / GF, tx0 = (tid - ry * GF) * KF;
+            const int ry = tid % EH, tx0 = (tid / EH) * KF;   // neighbouring lanes: neighbouring rows (see EWP)
             double cv[KF + 14];
 #pragma unroll
             for (int k = 0; k < KF + 14; k++) {
-                double v = bb[ry * EW + tx0 + k];
+                double v = bb[ry * EWP + tx0 + k];
                 cv[k] = squared ? v * v : v;
             }
 #pragma unroll
@@ -271,14 +274,14 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
                 double acc = 0.0;
 #pragma unroll
                 for (int j = 0; j < 15; j++) acc = acc + cv[o + j];
-                rs[ry * TX + tx0 + o] = acc;
+                rs[ry * RSP + tx0 + o] = acc;
             }
         }
     };
     auto col_sums = [&](double *res) {
         double cv[KG + 14];
 #pragma unroll
-        for (int k = 0; k < KG + 14; k++) cv[k] = rs[(oty0 + k) * TX + otx];
+        for (int k = 0; k < KG + 14; k++) cv[k] = rs[(oty0 + k) * RSP + otx];
 #pragma unroll
         for (int o = 0; o < KG; o++) {
             double acc = 0.0;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         if (var < 0) var = 0;
         double sd = sqrt(var);
         double T = m * (1 + 0.5 * ((sd / 128) - 1));
-        double bv = bb[(ty + RE) * EW + tx + RE];
+        double bv = bb[(ty + RE) * EWP + tx + RE];
         if (y < h && x < w) out[(size_t)y * w + x] = (bv > T) ? 0 : 255;
     }
 }
