@@ -29,6 +29,7 @@ constexpr int EW = TX + 2 * RE, EH = TY + 2 * RE;   // 78 x 78
 // LDS row strides (in doubles) of b and of the row sums: with lanes = rows, an odd stride spreads a 32-lane group's 8-byte
 // accesses over all 64 banks (stride 78 / 64 cost the row-sum phases 2x on reads and 8x on writes)
 constexpr int EWP = EW + 1, RSP = TX + 1;
+constexpr int VWP = VW + 1, GWP = GW_ + 1;          // the same for V and G (x-Gaussian: lanes = rows)
 
 __constant__ double c_gw[13] = {
     0x1.105a329f98197p-3, 0x1.01a25f86eb137p-3, 0x1.b42a57d56c0bep-4,
@@ -40,17 +41,17 @@ __constant__ double c_gw[13] = {
 struct Smem {
     uint8_t a[AH * AW + 16];   // + slack: the last strip of phase B reads one dword past its row
     uint8_t b5[BH * BW];
-    double buf1[VH * VW];  // V, later b
-    double buf2[GH * GW_]; // G, later row sums
+    double buf1[VH * VWP];  // V, later b
+    double buf2[GH * GWP];  // G, later row sums
 };
 static_assert(sizeof(Smem) <= 160 * 1024, "LDS budget");
-static_assert(EH * EWP <= VH * VW && EH * RSP <= GH * GW_, "buffer reuse");
+static_assert(EH * EWP <= VH * VWP && EH * RSP <= GH * GWP, "buffer reuse");
 
 // np.gradient of G (LDS tile, global coords) -- one-sided at the image border
 struct GView {
     const double *g;
     int x0, y0, w, h;  // global coords of local (0,0); image size
-    __device__ __forceinline__ double at(int y, int x) const { return g[(y - y0) * GW_ + (x - x0)]; }
+    __device__ __forceinline__ double at(int y, int x) const { return g[(y - y0) * GWP + (x - x0)]; }
     __device__ __forceinline__ double gx(int y, int x) const
     {
         if (x == 0) return at(y, 1) - at(y, 0);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
                             tsum = tsum + pr;
                         }
                     }
-                    s.buf1[ry * VW + rx] = tsum;
+                    s.buf1[ry * VWP + rx] = tsum;
                 }
             }
         }
@@ -185,11 +186,11 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         constexpr int KD = 7, GD = (GW_ + KD - 1) / KD;   // 12 column groups x 82 rows = 984 threads busy
         static_assert(GD * GH <= NT, "phase D fits one round");
         if (tid < GD * GH) {
-            const int ry = tid / GD, grp = tid - ry * GD;
+            const int ry = tid % GH, grp = tid / GH;   // neighbouring lanes: neighbouring rows (odd strides: no bank conflicts)
             const int rx0 = grp * KD;
             double cv[KD + 24];
 #pragma unroll
-            for (int k = 0; k < KD + 24; k++) cv[k] = (rx0 + k < VW) ? s.buf1[ry * VW + rx0 + k] : 0.0;
+            for (int k = 0; k < KD + 24; k++) cv[k] = (rx0 + k < VW) ? s.buf1[ry * VWP + rx0 + k] : 0.0;
 #pragma unroll
             for (int o = 0; o < KD; o++) {
                 if (rx0 + o < GW_) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
                         double pr = sm * c_gw[j];
                         tsum = tsum + pr;
                     }
-                    s.buf2[ry * GW_ + rx0 + o] = tsum;
+                    s.buf2[ry * GWP + rx0 + o] = tsum;
                 }
             }
         }
@@ -219,11 +220,11 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
             int y = cpe::clampi(gy0 - RE + ry, 0, h - 1), x = cpe::clampi(gx0 - RE + rx, 0, w - 1);
             double m00, m01, m11;
             if (inner) {
-                const double *g = &s.buf2[(ry + RG - RE) * GW_ + rx + RG - RE];   // G at (y, x)
+                const double *g = &s.buf2[(ry + RG - RE) * GWP + rx + RG - RE];   // G at (y, x)
                 const double c = g[0];
                 m00 = ((g[2] - c) / 2.0 - (c - g[-2]) / 2.0) / 2.0;
-                m01 = ((g[GW_ + 1] - g[GW_ - 1]) / 2.0 - (g[-GW_ + 1] - g[-GW_ - 1]) / 2.0) / 2.0;
-                m11 = ((g[2 * GW_] - c) / 2.0 - (c - g[-2 * GW_]) / 2.0) / 2.0;
+                m01 = ((g[GWP + 1] - g[GWP - 1]) / 2.0 - (g[-GWP + 1] - g[-GWP - 1]) / 2.0) / 2.0;
+                m11 = ((g[2 * GWP] - c) / 2.0 - (c - g[-2 * GWP]) / 2.0) / 2.0;
             } else {
                 if (x == 0) m00 = G.gx(y, 1) - G.gx(y, 0);
                 else if (x == w - 1) m00 = G.gx(y, w - 1) - G.gx(y, w - 2);
