@@ -48,7 +48,7 @@ static_assert(P_COUNT <= 64, "Layout arrays too small");
 
 // capacities of the blob sweep that grow with the frame (border points per threshold ~ cells x perimeter)
 static int region_maxch(int h, int w) { long long v = (long long)h * w / 256; return (int)std::min(65535LL, std::max(8192LL, v)); }
-static int region_maxdf(int h, int w) { long long v = (long long)h * w / 8; return (int)std::max(131072LL, v); }
+static int region_maxdf(int h, int w) { long long v = (long long)h * w / 16; return (int)std::max(65536LL, v); }   // x 17, pooled
 
 Layout make_layout(int n, int h, int w)
 {

@@ -206,7 +206,8 @@ constexpr int CH_PTS = 31;
 // chunks per frame and threshold: RegionBuffers::maxch = clamp(h*w/256, 8192, 65535) (ids are stored as u16)
 constexpr int MAXCHAIN = 512;          // chunks of one border the median kernel can index (15 872 points)
 constexpr int PTS_STORED = 0x40000000; // blob_d[2 bi] = last chunk | PTS_STORED, else offset into the distance scratch
-// distance scratch (double) per frame and threshold (bright blobs, fall-backs): RegionBuffers::maxdf = max(65536, h*w/32)
+// distance scratch (double) per frame, shared by the 17 thresholds (bright blobs, fall-backs; a noisy frame needs nearly all
+// of it at the lowest threshold): NTHR * RegionBuffers::maxdf entries, one counter (SW_ND + 0)
 constexpr int CH_DIRECT = 16;          // chunk ids kept with the blob record: borders up to 496 points need no chain walk
 
 struct StoreVisitor {
@@ -279,7 +280,7 @@ __device__ __forceinline__ void blob_trace_one(int f, int slot, int k, int h, in
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
     if (e.y >= 5000) return;
     int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
-    double *dists = dists_all + ((size_t)f * NTHR + slot) * maxdf;
+    double *dists = dists_all + (size_t)f * NTHR * maxdf;
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     int y0 = root / w, x0 = root - y0 * w;
     if (is_hole) x0 -= 1;
@@ -314,8 +315,8 @@ __device__ __forceinline__ void blob_trace_one(int f, int slot, int k, int h, in
         unsigned short *ch = blob_ch_all + (((size_t)f * NTHR + slot) * MAXB + bi) * CH_DIRECT;
         for (int j = 0; j < min(tv.nch, CH_DIRECT); j++) ch[j] = s_ids[j * 64 + threadIdx.x];
     } else {
-        int doff = atomicAdd(&S[SW_ND + slot], sv.npts);
-        if (doff + sv.npts > maxdf) { set_overflow(st[f], OVF_DISTS); blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
+        int doff = atomicAdd(&S[SW_ND], sv.npts);
+        if ((long long)doff + sv.npts > (long long)NTHR * maxdf) { set_overflow(st[f], OVF_DISTS); blob_d[bi * 2] = -1; blob_d[bi * 2 + 1] = 0; }
         else {
             DistVisitor dv{cx, cy, dists + doff};
             trace_border(nz, x0, y0, is_hole != 0, dv, max_steps);
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
     const int nb = part ? min(S[SW_NB + slot], MAXB) : S[SW_NA + slot];
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
-    double *dists = dists_all + ((size_t)f * NTHR + slot) * maxdf;
+    double *dists = dists_all + (size_t)f * NTHR * maxdf;
     const uint32_t *pool = pool_all + ((size_t)f * NTHR + slot) * maxch * 32;
     const unsigned short *blob_ch = blob_ch_all + ((size_t)f * NTHR + slot) * MAXB * CH_DIRECT;
     for (int bi = (part ? S[SW_NA + slot] : 0) + blockIdx.x; bi < nb; bi += gridDim.x) {
