@@ -109,7 +109,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--frames', type=int, default=4096, help='stereo frames per GPU per step')
     ap.add_argument('--chunk', type=int, default=0,
-                    help='stereo frames per kernel batch (workspace size); 0 = 256 at 1920x1200 (~170 GiB of workspace), 64 at 3840x2160')
+                    help='stereo frames per kernel batch (workspace size); 0 = 256 at 1920x1200 (~160 GiB of workspace), 64 at 3840x2160')
     ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes per GPU (cycled with fresh noise)')
     ap.add_argument('--fit-mode', choices=['nm', 'lm'], default='nm',
                     help='nm = fminsearch clone (reference behaviour, default); lm = Levenberg-Marquardt fast mode')
