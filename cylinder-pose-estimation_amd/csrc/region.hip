@@ -1152,38 +1152,41 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
 __global__ __launch_bounds__(256) void k_discs(FrameState *__restrict__ st, const Group *__restrict__ groups, int h, int w,
                                                uint8_t *__restrict__ ext)
 {
-    const int f = blockIdx.y;
-    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= min(st[f].n_groups, MAXG)) return;
-    const Group &g = groups[(size_t)f * MAXG + gi];
-    if (g.n < 2) return;
-    double sx = 0, sy = 0, nrm = 0;
-    for (int j = 0; j < g.n; j++) { sx += 1.0 * g.c[j][0]; sy += 1.0 * g.c[j][1]; nrm += 1.0; }
-    sx *= (1. / nrm);
-    sy *= (1. / nrm);
-    float kx = (float)sx, ky = (float)sy, ksize = (float)(g.c[g.n / 2][2]) * 2.0f;
-    float radius = ksize / 2;
-    int er = (int)((double)radius + 4);
-    int cx = (int)kx, cy = (int)ky;
-    atomicAdd(&st[f].n_kp, 1);
+    // one wavefront per group, in turns: lane 0's arithmetic is cv2's, the lanes share the pixels of each span
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int ng = min(st[f].n_groups, MAXG);
     uint8_t *im = ext + (size_t)f * h * w;
-    int err = 0, dx = er, dy = 0, plus = 1, minus = (er << 1) - 1;
-    while (dx >= dy) {
-        int ys[4] = {cy - dy, cy + dy, cy - dx, cy + dx};
-        int xa[4] = {cx - dx, cx - dx, cx - dy, cx - dy};
-        int xb[4] = {cx + dx, cx + dx, cx + dy, cx + dy};
-        for (int q = 0; q < 4; q++) {
-            if (ys[q] < 0 || ys[q] >= h) continue;
-            int x1 = max(xa[q], 0), x2 = min(xb[q], w - 1);
-            for (int x = x1; x <= x2; x++) im[(size_t)ys[q] * w + x] = 255;
+    for (int gi = blockIdx.x * 4 + (threadIdx.x >> 6); gi < ng; gi += gridDim.x * 4) {
+        const Group &g = groups[(size_t)f * MAXG + gi];
+        const int gn = g.n;
+        if (gn < 2) continue;
+        double sx = 0, sy = 0, nrm = 0;
+        for (int j = 0; j < gn; j++) { sx += 1.0 * g.c[j][0]; sy += 1.0 * g.c[j][1]; nrm += 1.0; }
+        sx *= (1. / nrm);
+        sy *= (1. / nrm);
+        float kx = (float)sx, ky = (float)sy, ksize = (float)(g.c[gn / 2][2]) * 2.0f;
+        float radius = ksize / 2;
+        int er = (int)((double)radius + 4);
+        int cx = (int)kx, cy = (int)ky;
+        if (lane == 0) atomicAdd(&st[f].n_kp, 1);
+        int err = 0, dx = er, dy = 0, plus = 1, minus = (er << 1) - 1;
+        while (dx >= dy) {
+            int ys[4] = {cy - dy, cy + dy, cy - dx, cy + dx};
+            int xa[4] = {cx - dx, cx - dx, cx - dy, cx - dy};
+            int xb[4] = {cx + dx, cx + dx, cx + dy, cx + dy};
+            for (int q = 0; q < 4; q++) {
+                if (ys[q] < 0 || ys[q] >= h) continue;
+                int x1 = max(xa[q], 0), x2 = min(xb[q], w - 1);
+                for (int x = x1 + lane; x <= x2; x += 64) im[(size_t)ys[q] * w + x] = 255;
+            }
+            dy++;
+            err += plus;
+            plus += 2;
+            int mask = (err <= 0) - 1;
+            err -= minus & mask;
+            dx += mask;
+            minus -= mask & 2;
         }
-        dy++;
-        err += plus;
-        plus += 2;
-        int mask = (err <= 0) - 1;
-        err -= minus & mask;
-        dx += mask;
-        minus -= mask & 2;
     }
 }
 
@@ -1530,7 +1533,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
-    CPE_KLAUNCH(k_discs, dim3(MAXG / 256, n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
+    CPE_KLAUNCH(k_discs, dim3(frame_waves(n, 4, MAXG / 4), n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
     if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     if ((rc = build_bitplanes(B.ext, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
