@@ -60,3 +60,53 @@ def test_pack_counters_roundtrip():
     got = P.unpack_counters(P.pack_counters(n, it, fs, dl, dr))
     for a, b in zip(got, (n, it, fs, dl, dr)):
         assert a.tolist() == b.tolist()
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], env=e, capture_output=True, timeout=300)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()
+
+
+def test_bench_starts_its_own_ranks_strong_scaling():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the parent starts two ranks, each owns its
+    dist.shard_range block of THE batch, the records of all frames come back in order (gloo, stub pipeline)"""
+    rc, out, err = _bench('--gpus', '2', '--stub', '--frames', '11', '--steps', '2', '--warmup', '1')
+    assert rc == 0, err
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['steps'] == 2
+    assert out['config']['frames_total'] == 11 and out['config']['frames_per_gpu'] == 6
+    assert out['rows'] == 11 and out['checksum'] == float(sum(range(11)))
+    assert out['all_gather_bytes'] == 11 * 128
+    rc1, one, err1 = _bench('--gpus', '1', '--stub', '--frames', '11', '--steps', '2', '--warmup', '1')
+    assert rc1 == 0, err1
+    assert one['payload_sum'] == out['payload_sum']          # same batch whatever the number of ranks
+    assert one['scaling'] == 'weak' and one['n_gpus'] == 1
+
+
+def test_bench_weak_scaling_and_rank_failure():
+    rc, out, err = _bench('--gpus', '2', '--stub', '--frames', '5', '--scaling', 'weak', '--steps', '1', '--warmup', '0')
+    assert rc == 0, err
+    assert out['scaling'] == 'weak' and out['config']['frames_total'] == 10 and out['rows'] == 10
+    # a world size that contradicts --gpus is refused (torchrun form with the wrong -nproc)
+    rc, out, err = _bench('--gpus', '2', '--stub', env=dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert rc != 0 and out is None
+
+
+def test_bench_under_torchrun_form():
+    """the driver's form: ranks started by torch.distributed.run, RANK / WORLD_SIZE in the environment"""
+    import json
+    import subprocess
+    e = dict(os.environ)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub', '--frames', '9', '--steps', '1', '--warmup', '0'],
+                       env=e, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['rows'] == 9 and out['checksum'] == 36.0
