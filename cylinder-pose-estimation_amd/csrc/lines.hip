@@ -12,7 +12,7 @@ namespace cpe {
 
 struct LinesWS {
     double gpts[2][MAXL][MAXLP][2];  // joints per line (rows = side 0, cols = side 1)
-    double ipts[2][MAXL][MAXLP][2];  // intersections per line
+    double ipts[2][MAXL][MAXL][2];   // intersections per line: at most one per line of the other direction
     double eq[2][MAXL][6];
     double ixy[MAXL][MAXL][2];
     double key[2][MAXL];
@@ -485,6 +485,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         s_n[sd] = n;
     }
     __syncthreads();
+    // a truncated joint list changes everything downstream: flag it now, the early returns below must not hide it
+    if (t == 0 && s_ovf) set_overflow(S, OVF_LINES);
     const int nr = s_n[0], nc = s_n[1];
     if (subpixel) {
         // modify_grayscale_Cline(gray, rows, cols, degree 2, sample_step, window): sample every fitted line, pull each
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             }
         }
         __syncthreads();
+        if (t == 0 && s_ovf) set_overflow(S, OVF_LINES);
         if (s_raise) {
             if (t == 0) S.status = CPE_ST_SUBPIXEL_RAISED;
             return;
@@ -571,12 +574,10 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             for (int q = 0; q < other; q++) {
                 int r = sd == 0 ? pos : q, c = sd == 0 ? q : pos;
                 if (!W.ival[r][c]) continue;
-                if (k < MAXLP) {
-                    W.ipts[sd][slot][k][0] = W.ixy[r][c][0];
-                    W.ipts[sd][slot][k][1] = W.ixy[r][c][1];
-                    sum += W.ixy[r][c][sd == 0 ? 1 : 0];
-                    k++;
-                }
+                W.ipts[sd][slot][k][0] = W.ixy[r][c][0];   // k < other <= MAXL
+                W.ipts[sd][slot][k][1] = W.ixy[r][c][1];
+                sum += W.ixy[r][c][sd == 0 ? 1 : 0];
+                k++;
             }
             W.in[sd][slot] = k;
             W.key[sd][slot] = k > 0 ? sum / k : 0.0;
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         double bd = 1e300;
         int bi = INT_MAX;
         const int nl = side == 0 ? NR : NC;
-        // flattened order index = (line position << 8) | point index  (MAXLP <= 256)
+        // flattened order index = (line position << 8) | point index  (MAXL <= 256 points per line)
         for (int ln = 0; ln < nl; ln++) {
             const int slot = s_ord[side][ln];
             const int np = W.in[side][slot];

@@ -130,3 +130,29 @@ def test_plane_entry_module_folder(cpe, orc, gpu, tmp_path):
     assert [p['id'] for p in pts] == ref['id'].tolist()
     assert np.array_equal(np.array([[p['x'], p['y']] for p in pts]), ref['xy'])
     assert res['img_L_000']['center_point'] == ref['center'].tolist()
+
+
+@pytest.mark.gpu
+def test_more_than_64_lines_in_one_direction(cpe, orc, gpu):
+    """85 columns cross every row: per-line joint and intersection lists longer than 64 entries (the first sizing of the
+    tables truncated them silently).  Both scripts, GPU == oracle; an overflow would have to say so (status 6)."""
+    from cpe_amd import synth
+    from oracle import stages as S
+    h, w = 520, 2700
+    sc = synth.Scene(h=h, w=w, radius=5000.0, depth=(5340.0, 5400.0), tilt_deg=2.0, pitch_px=30.0, half_lines=42, half_lines_v=4)
+    b = synth.render_batch(1, h, w, seed=4, scene=sc, with_gt=False)
+    frames = torch.cat([b['left'], b['right']])
+    for target, fn in (('plane', S.detect_grid_plane), ('cylinder', S.detect_grid)):
+        det = cpe.api.detect_grid_batch(frames.to(gpu), target=target)
+        torch.cuda.synchronize()
+        state = det['ws'].state()
+        for i in range(2):
+            ref = fn(frames[i].numpy(), debug=True)
+            assert ref['status'] == 0 and ref['n_cols'] > 64
+            assert int(det['status'][i]) == 0, (target, i, state[i]['overflow'])
+            assert (state[i]['n_rows'], state[i]['n_cols']) == (ref['n_rows'], ref['n_cols'])
+            m = int(det['n'][i])
+            assert m == len(ref['xy'])
+            assert np.array_equal(det['id'][i, :m].cpu().numpy(), ref['id'])
+            assert np.array_equal(det['xy'][i, :m].cpu().numpy(), ref['xy'])
+            assert np.array_equal(det['center'][i].cpu().numpy(), ref['center'])
