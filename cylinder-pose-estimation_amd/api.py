@@ -3,7 +3,8 @@
 `detect_grid_batch` is the MI355X-native form of python_grid_detection_cylinder.py::detect_grid
 (:68-112): all frames of a batch go through the HIP kernels behind the C ABI (include/cpe.h) and come
 back as padded point tables; `detect_grid(input_img)` keeps the reference's single-image signature and
-return shape, `make_json` its JSON (util_cylinder.py:1674-1727, decoded by makePyGridPts.m:39-41).
+return shape, `make_json` its JSON (util_cylinder.py:1674-1727, decoded by makePyGridPts.m:39-41), `save_mat`
+writes the structs the MATLAB side holds after makePyGridPts / fitSingleCylinder.
 There is no CPU fallback: without a GPU and libcpe_hip.so these raise."""
 import ctypes as C
 import json
@@ -102,40 +103,141 @@ def make_json(center, xy, ids):
     return json.dumps({"center_point": [float(center[0]), float(center[1])], "points": pts}, indent=4, ensure_ascii=False)
 
 
-def to_gray(input_img):
-    """2-D grey array, or H x W x 3 BGR with identical channels (what cv2.imread gives for a mono camera)"""
-    a = np.asarray(input_img)
-    if a.dtype != np.uint8:
-        raise TypeError('detect_grid expects uint8 images')
-    if a.ndim == 2:
-        return a
-    if a.ndim == 3 and a.shape[2] == 3:
-        if not (np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 1], a[..., 2])):
-            raise NotImplementedError('colour frames are outside the scope of this build (grey / grey-replicated only)')
-        return np.ascontiguousarray(a[..., 0])
-    raise ValueError(f'Unexpected input dimensions: {a.ndim}')
+def bgr_to_gray(bgr):
+    """u8 tensor [n,h,w,3] (BGR, interleaved) on the GPU -> u8 [n,h,w]: cv2.cvtColor(BGR2GRAY) of
+    load_and_preprocess_image (util_cylinder.py:1781-1789), cpe_bgr2gray_batch"""
+    if not (isinstance(bgr, torch.Tensor) and bgr.is_cuda and bgr.dtype == torch.uint8 and bgr.dim() == 4 and bgr.shape[3] == 3):
+        raise TypeError('bgr must be a CUDA uint8 tensor [n,h,w,3]')
+    bgr = bgr.contiguous()
+    n, h, w, _ = bgr.shape
+    gray = torch.empty((n, h, w), dtype=torch.uint8, device=bgr.device)
+    with torch.cuda.device(bgr.device):
+        _lib.check(_lib.load().cpe_bgr2gray_batch(bgr.data_ptr(), n, h, w, gray.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   'cpe_bgr2gray_batch')
+    return gray
+
+
+def frames_to_device(images, device='cuda:0'):
+    """list of numpy u8 images of one size, each H x W (grey) or H x W x 3 (BGR as cv2.imread gives it) -> u8 tensor [n,h,w]
+    on the device.  3-channel frames go through the BGR2GRAY kernel (identity for a mono camera's replicated channels)."""
+    arrs = [np.asarray(a) for a in images]
+    for a in arrs:
+        if a.dtype != np.uint8:
+            raise TypeError('detect_grid expects uint8 images')
+        if not (a.ndim == 2 or (a.ndim == 3 and a.shape[2] == 3)):
+            raise ValueError(f'Unexpected input dimensions: {a.ndim}')        # util_cylinder.py:1788
+    out = torch.empty((len(arrs),) + arrs[0].shape[:2], dtype=torch.uint8, device=device)
+    col = [i for i, a in enumerate(arrs) if a.ndim == 3]
+    mono = [i for i, a in enumerate(arrs) if a.ndim == 2]
+    if mono:
+        out[mono] = torch.from_numpy(np.stack([arrs[i] for i in mono])).to(device)
+    if col:
+        out[col] = bgr_to_gray(torch.from_numpy(np.stack([np.ascontiguousarray(arrs[i]) for i in col])).to(device))
+    return out
+
+
+def line_tables(det, frame, target='cylinder'):
+    """rows_updated, cols_updated of one frame of a detect_grid_batch result: the third and fourth return values of the
+    reference's detect_grid (built by find_and_assign_intersections_P + clean_and_relabel, util_cylinder.py:1106-1206):
+    {'points': {'row1': [(x, y), ...], ...}, 'equations': {'row1': [a2, a1, a0, lo, hi, span], ...}}"""
+    ws = det['ws']
+    dev = det['xy'].device
+    ML = _lib.MAXL
+    eq = torch.empty((2, ML, 6), dtype=torch.float64, device=dev)
+    npts = torch.empty((2, ML), dtype=torch.int32, device=dev)
+    pts = torch.empty((2, ML, ML, 2), dtype=torch.float64, device=dev)
+    nl = torch.empty(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().cpe_detect_line_tables(ws.view.data_ptr(), ws.bytes, ws.n, ws.h, ws.w, int(frame), eq.data_ptr(),
+                                                      npts.data_ptr(), pts.data_ptr(), nl.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), 'cpe_detect_line_tables')
+    eq, npts, pts, nl = eq.cpu().numpy(), npts.cpu().numpy(), pts.cpu().numpy(), nl.cpu().numpy()
+    out = []
+    for sd, prefix in ((0, 'row'), (1, 'col')):
+        d = {'points': {}, 'equations': {}}
+        for g in range(int(nl[sd])):
+            d['points'][f'{prefix}{g + 1}'] = [(float(x), float(y)) for x, y in pts[sd, g, :npts[sd, g]]]
+            d['equations'][f'{prefix}{g + 1}'] = [float(v) for v in eq[sd, g]]
+        out.append(d)
+    return out[0], out[1]
+
+
+def draw_points(gray, xy):
+    """the returned picture: BGR copy of the frame with the grid points marked (deterministic; the reference draws random
+    colours, util_cylinder.py:1600-1601)"""
+    col_img = np.repeat(np.asarray(gray)[..., None], 3, axis=2)
+    for (x, y) in xy:
+        xi, yi = int(x), int(y)
+        col_img[max(yi - 2, 0):yi + 3, max(xi - 2, 0):xi + 3] = (0, 255, 0)
+    return col_img
+
+
+def frame_result(det, k, gray, target='cylinder'):
+    """the 4-tuple detect_grid returns for frame k of a batch result, or None (after printing why) for a failed frame"""
+    st = int(det['status'][k])
+    if st != 0:
+        print(f'Error in detect_grid: {STATUS_TEXT.get(st, st)}')
+        return None
+    m = int(det['n'][k])
+    xy = det['xy'][k, :m].cpu().numpy(); ids = det['id'][k, :m].cpu().numpy(); center = det['center'][k].cpu().numpy()
+    rows, cols = line_tables(det, k, target)
+    return draw_points(gray, xy), make_json(center, xy, ids), rows, cols
 
 
 def detect_grid(input_img, device='cuda:0', target='cylinder'):
     """detect_grid(input_img) -> (col_img, result_json, rows_updated, cols_updated)
     (python_grid_detection_cylinder.py:68-110; target='plane': python_grid_detection_plane.py:74-119, whose ids are
     (row, col)).  On a per-frame failure prints and returns None (:111-112)."""
-    gray = to_gray(input_img)
-    det = detect_grid_batch(torch.from_numpy(gray).to(device)[None], target=target)
-    st = int(det['status'][0])
-    if st != 0:
-        print(f'Error in detect_grid: {STATUS_TEXT.get(st, st)}')
-        return None
-    m = int(det['n'][0])
-    xy = det['xy'][0, :m].cpu().numpy(); ids = det['id'][0, :m].cpu().numpy(); center = det['center'][0].cpu().numpy()
-    col_img = np.repeat(gray[..., None], 3, axis=2)
-    for (x, y) in xy:                       # deterministic drawing (the reference's colours are random)
-        xi, yi = int(x), int(y)
-        col_img[max(yi - 2, 0):yi + 3, max(xi - 2, 0):xi + 3] = (0, 255, 0)
-    cols = {}
-    rows = {}
-    for (x, y), (i0, i1) in zip(xy, ids):
-        c, r = (i1, i0) if target == 'plane' else (i0, i1)
-        cols.setdefault(f'col{int(c) + 1}', []).append((float(x), float(y)))
-        rows.setdefault(f'row{int(r)}', []).append((float(x), float(y)))
-    return col_img, make_json(center, xy, ids), {'points': rows, 'equations': {}}, {'points': cols, 'equations': {}}
+    frames = frames_to_device([input_img], device)
+    det = detect_grid_batch(frames, target=target)
+    return frame_result(det, 0, frames[0].cpu().numpy(), target)
+
+
+def grid_struct(det, k):
+    """gridPts of makePyGridPts.m:39-41 for frame k: center_point (2 x 1), points (N x 4 = [x y colIdx rowIdx])"""
+    m = int(det['n'][k])
+    xy = det['xy'][k, :m].cpu().numpy(); ids = det['id'][k, :m].cpu().numpy().astype(np.float64)
+    return dict(center_point=det['center'][k].cpu().numpy().reshape(2, 1), points=np.concatenate([xy, ids], 1).reshape(-1, 4))
+
+
+def save_mat(path, grid_left=None, grid_right=None, fits=None, names=None):
+    """the .mat hand-off of SURVEY 8(b): what the MATLAB pipeline holds after makePyGridPts (gridPtsPair) and
+    fitSingleCylinder, written with scipy.io.savemat so `load(path)` gives the same variables.
+
+        gridPtsPair  F x 2 struct array, fields center_point (2 x 1), points (N x 4 [x y colIdx rowIdx])
+                     (makePyGridPts.m:39-41, pointsStruct2mat.m:16; column 1 = left image, 2 = right)
+        frames       1 x F struct array, fields pts3 (3 x N), cylParams (2 x 6 = [cylParams0; cylParams]), cylT (4 x 4),
+                     fvals (1 x 2), meanError (scalar), status        (fitSingleCylinder.m:1, fitCylinderWPts3.m:41)
+        names        F x 1 cell of the image stems (getUniqueName.m)
+
+    grid_left / grid_right: lists of dict(center_point, points) (api.grid_struct); fits: the dict
+    fit.fit_single_cylinder_batch returns."""
+    from scipy.io import savemat
+    out = {}
+    if grid_left is not None:
+        F = len(grid_left)
+        if grid_right is not None and len(grid_right) != F:
+            raise ValueError('save_mat: left and right tables differ in length')
+        pair = np.zeros((F, 2 if grid_right is not None else 1), dtype=[('center_point', 'O'), ('points', 'O')])
+        for i in range(F):
+            for c, g in enumerate((grid_left, grid_right) if grid_right is not None else (grid_left,)):
+                pair[i, c]['center_point'] = np.asarray(g[i]['center_point'], np.float64).reshape(2, 1)
+                pair[i, c]['points'] = np.asarray(g[i]['points'], np.float64).reshape(-1, 4)
+        out['gridPtsPair'] = pair
+    if fits is not None:
+        m = fits['m'].cpu().numpy(); F = len(m)
+        pts3 = fits['pts3'].cpu().numpy(); cyl = fits['cyl'].cpu().numpy(); T = fits['T'].cpu().numpy()
+        fv = fits['fvals'].cpu().numpy(); me = fits['mean_err'].cpu().numpy(); st = fits['status'].cpu().numpy()
+        fr = np.zeros((1, F), dtype=[(k, 'O') for k in ('pts3', 'cylParams', 'cylT', 'fvals', 'meanError', 'status')])
+        for i in range(F):
+            fr[0, i]['pts3'] = np.ascontiguousarray(pts3[i, :m[i]].T)
+            fr[0, i]['cylParams'] = cyl[i].reshape(2, 6)
+            fr[0, i]['cylT'] = T[i].reshape(4, 4)
+            fr[0, i]['fvals'] = fv[i].reshape(1, 2)
+            fr[0, i]['meanError'] = float(me[i])
+            fr[0, i]['status'] = float(st[i])
+        out['frames'] = fr
+    if names is not None:
+        out['names'] = np.array(list(names), dtype=object).reshape(-1, 1)
+    savemat(path, out, oned_as='column')
+    return path

@@ -30,6 +30,8 @@ int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const 
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
                 int subpixel, int sp_window, double sp_step, float *sp_scratch, int sp_cap, hipStream_t s, int planar);
 
+int lines_export(const void *lines_ws, int f, double *eq, int *npts, double *pts, int *n_lines, hipStream_t s);
+
 namespace {
 
 struct Layout {
@@ -126,6 +128,7 @@ __global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
 
 // two helper streams per process (created on first use; CPE_SERIAL=1 keeps everything on the caller's stream)
 struct SideStreams {
+    std::mutex mu;      // held by a caller from its fork to its join (cpe_detect_grid_batch_ex)
     bool ok = false;
     hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
     hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, e3a = nullptr, e3b = nullptr, e3c = nullptr, e3d = nullptr;
@@ -230,43 +233,110 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
     M.lab_p = PL(int, P_LABP); M.lab_s = PL(int, P_LABS); M.roots_p = PL(int, P_ROOTSP); M.roots_s = PL(int, P_ROOTSS);
     M.best_s = PL(unsigned long long, P_BEST2);
-    int rc;
-    CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
-    CPE_CHECK_LAUNCH("k_state_init");
     // three chains that only meet in masks_stage: ridge mask -> line masks -> joints (stream 1), saturated spot
     // (stream 2), region (the caller's stream).  The side chains are mostly ALU / latency bound and fill the CUs the
-    // region stage's serial kernels leave idle.
+    // region stage's serial kernels leave idle.  The helper streams and their events are per device and shared by all
+    // callers: the enqueue below (fork .. join, host side only, microseconds per kernel) runs under the device's mutex,
+    // so two host threads never interleave their forks and joins.
     SideStreams &X = side_streams();
-    if (X.ok) {
-        (void)hipEventRecord(X.fork, s);
-        (void)hipStreamWaitEvent(X.s1, X.fork, 0);
-        (void)hipStreamWaitEvent(X.s2, X.fork, 0);
+    std::unique_lock<std::mutex> lk(X.mu, std::defer_lock);
+    if (X.ok) lk.lock();
+    bool forked = false;
+    auto enqueue = [&]() -> int {
+        int rc;
+        CPE_LAUNCH_BEGIN();
+        CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+        CPE_CHECK_LAUNCH("k_state_init");
+        if (X.ok) {
+            CPE_CHECK_HIP(hipEventRecord(X.fork, s));
+            CPE_CHECK_HIP(hipStreamWaitEvent(X.s1, X.fork, 0));
+            CPE_CHECK_HIP(hipStreamWaitEvent(X.s2, X.fork, 0));
+            forked = true;
+        }
+        hipStream_t s1 = X.ok ? X.s1 : s, s2 = X.ok ? X.s2 : s;
+        if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
+        if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
+        if ((rc = spot_stage(gray, n, h, w, M, st, s2, planar)) != CPE_OK) return rc;
+        RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d};
+        if (planar) { if ((rc = region_stage_plane(gray, n, h, w, R, st, s)) != CPE_OK) return rc; }
+        else if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
+        if (X.ok) {
+            CPE_CHECK_HIP(hipEventRecord(X.join1, X.s1));
+            CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
+            CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join1, 0));
+            CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join2, 0));
+            forked = false;
+        }
+        M.lab_h = PL(int, P_LAB0); M.lab_v = PL(int, P_LAB1);
+        if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar)) != CPE_OK) return rc;
+        if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
+        if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
+                              n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
+                              std::max(h, w) + 128, s, planar)) != CPE_OK)
+            return rc;
+        CPE_LAUNCH_BEGIN();
+        CPE_KLAUNCH(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);
+        CPE_CHECK_LAUNCH("k_finish");
+        return CPE_OK;
+    };
+    const int rc = enqueue();
+    if (X.ok && (forked || rc != CPE_OK)) {
+        // an error between fork and join: whatever already runs on the helper streams still uses the caller's buffers,
+        // so the caller's stream is made to wait for all of them before the error is reported
+        hipStream_t hs[3] = {X.s1, X.s2, X.s3};
+        hipEvent_t he[3] = {X.join1, X.join2, X.e3a};
+        for (int k = 0; k < 3; k++)
+            if (hipEventRecord(he[k], hs[k]) == hipSuccess) (void)hipStreamWaitEvent(s, he[k], 0);
+        (void)hipGetLastError();
     }
-    hipStream_t s1 = X.ok ? X.s1 : s, s2 = X.ok ? X.s2 : s;
-    if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
-    if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
-    if ((rc = spot_stage(gray, n, h, w, M, st, s2, planar)) != CPE_OK) return rc;
-    RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d};
-    if (planar) { if ((rc = region_stage_plane(gray, n, h, w, R, st, s)) != CPE_OK) return rc; }
-    else if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
-    if (X.ok) {
-        (void)hipEventRecord(X.join1, X.s1);
-        (void)hipEventRecord(X.join2, X.s2);
-        (void)hipStreamWaitEvent(s, X.join1, 0);
-        (void)hipStreamWaitEvent(s, X.join2, 0);
-    }
-    M.lab_h = PL(int, P_LAB0); M.lab_v = PL(int, P_LAB1);
-    if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar)) != CPE_OK) return rc;
-    if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
-    if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
-                          n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
-                          std::max(h, w) + 128, s, planar)) != CPE_OK)
-        return rc;
-    CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_finish, dim3((n + 63) / 64), dim3(64), 0, s, st, n, status, n_pts);
-    CPE_CHECK_LAUNCH("k_finish");
+    return rc;
 #undef PL
+}
+
+extern "C" int32_t cpe_detect_line_tables(const void *ws, size_t ws_bytes, int32_t n, int32_t h, int32_t w, int32_t frame,
+                                          double *eq, int32_t *npts, double *pts, int32_t *n_lines, void *stream)
+{
+    CPE_CHECK_ARG(ws && eq && npts && pts && n_lines && n > 0 && frame >= 0 && frame < n && h >= 64 && w >= 64,
+                  "cpe_detect_line_tables: bad argument");
+    static_assert(CPE_MAXL == MAXL, "cpe.h and cpe_dev.h disagree on the line capacity");
+    Layout L = make_layout(n, h, w);
+    CPE_CHECK_ARG(ws_bytes >= L.total && ((uintptr_t)ws & 255) == 0, "cpe_detect_line_tables: not the workspace of an (n,h,w) call");
+    return lines_export((const uint8_t *)ws + L.off[P_LINES], frame, eq, npts, pts, n_lines, (hipStream_t)stream);
+}
+
+// BGR2GRAY of the entry point for colour input (load_and_preprocess_image, util_cylinder.py:1781-1789)
+namespace cpe { namespace {
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ bgr, size_t npx, uint8_t *__restrict__ gray)
+{
+    // 4 pixels (12 bytes in, 1 dword out) per thread; cv2.cvtColor 8-bit: (B*3735 + G*19235 + R*9798 + 2^14) >> 15
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t p0 = q * 4;
+    if (p0 >= npx) return;
+    if (p0 + 4 <= npx) {
+        const uint32_t *src = (const uint32_t *)(bgr + p0 * 3);     // p0 * 3 is a multiple of 12
+        const uint32_t a = src[0], b = src[1], c = src[2];
+        const uint32_t px[4][3] = {{a & 255, (a >> 8) & 255, (a >> 16) & 255}, {a >> 24, b & 255, (b >> 8) & 255},
+                                   {(b >> 16) & 255, b >> 24, c & 255}, {(c >> 8) & 255, (c >> 16) & 255, c >> 24}};
+        uint32_t out = 0;
+        for (int k = 0; k < 4; k++) out |= ((px[k][0] * 3735u + px[k][1] * 19235u + px[k][2] * 9798u + 16384u) >> 15) << (8 * k);
+        *(uint32_t *)(gray + p0) = out;
+    } else {
+        for (size_t p = p0; p < npx; p++)
+            gray[p] = (uint8_t)((bgr[3 * p] * 3735u + bgr[3 * p + 1] * 19235u + bgr[3 * p + 2] * 9798u + 16384u) >> 15);
+    }
+}
+} }
+
+extern "C" int32_t cpe_bgr2gray_batch(const uint8_t *bgr, int32_t n, int32_t h, int32_t w, uint8_t *gray, void *stream)
+{
+    CPE_CHECK_ARG(bgr && gray && n >= 0 && h > 0 && w > 0, "cpe_bgr2gray_batch: bad argument");
+    CPE_CHECK_ARG(((uintptr_t)bgr & 3) == 0 && ((uintptr_t)gray & 3) == 0, "cpe_bgr2gray_batch: buffers must be 4-byte aligned");
+    if (n == 0) return CPE_OK;
+    const size_t npx = (size_t)n * h * w;
+    const size_t quads = (npx + 3) / 4;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_bgr2gray, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bgr, npx, gray);
+    CPE_CHECK_LAUNCH("k_bgr2gray");
     return CPE_OK;
 }
 

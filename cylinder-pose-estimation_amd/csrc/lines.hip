@@ -20,6 +20,7 @@ struct LinesWS {
     int ent_id[MAXL * MAXL][2];
     int gn[2][MAXL], in[2][MAXL], glabel[2][MAXL];
     unsigned char ival[MAXL][MAXL];
+    int fin_ord[2][MAXL], fin_n[2];  // lines that survive clean_and_relabel, in their final order (row1.., col1..)
 };
 
 size_t lines_ws_bytes() { return align_up(sizeof(LinesWS), 256); }
@@ -325,9 +326,9 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     __shared__ double s_rv[256];
     __shared__ int s_ri[256];
     __shared__ int s_crow, s_ccol, s_total;
-    if (t == 0) { o_n[f] = 0; o_center[2 * f] = 0; o_center[2 * f + 1] = 0; }
-    if (S.status != CPE_ST_OK) return;
     LinesWS &W = wsall[f];
+    if (t == 0) { o_n[f] = 0; o_center[2 * f] = 0; o_center[2 * f + 1] = 0; W.fin_n[0] = 0; W.fin_n[1] = 0; }
+    if (S.status != CPE_ST_OK) return;
     const size_t N = (size_t)h * w;
     // union-find planes of the two expanded masks (unions done, not flattened): only the joints' labels are resolved
     const int *L[2] = {lab_h + f * N, lab_v + f * N};
@@ -591,6 +592,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             if (W.in[sd][s_ord[sd][k]] > 0) s_ord[sd][n++] = s_ord[sd][k];
         if (!planar) sort_by_key(s_ord[sd], n, W.key[sd]);   // util_plane.py's clean_and_relabel keeps the order
         s_n[sd] = n;
+        for (int k = 0; k < n; k++) W.fin_ord[sd][k] = s_ord[sd][k];
+        W.fin_n[sd] = n;
     }
     __syncthreads();
     const int NR = s_n[0], NC = s_n[1];
@@ -746,7 +749,41 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     }
 }
 
+// rows_updated / cols_updated of one frame (what color_and_expand_lines returns beside the JSON, util_cylinder.py:2044-2060):
+// per surviving line, in final order, its equation and its intersection list in loop order
+__global__ __launch_bounds__(256) void k_line_tables(const LinesWS *__restrict__ wsall, int f, double *__restrict__ eq,
+                                                     int *__restrict__ npts, double *__restrict__ pts, int *__restrict__ n_lines)
+{
+    const LinesWS &W = wsall[f];
+    const int t = threadIdx.x;
+    if (t < 2) n_lines[t] = W.fin_n[t];
+    for (int i = t; i < 2 * MAXL; i += 256) {
+        const int sd = i / MAXL, pos = i % MAXL;
+        const bool live = pos < W.fin_n[sd];
+        const int slot = live ? W.fin_ord[sd][pos] : 0;
+        npts[i] = live ? W.in[sd][slot] : 0;
+        for (int k = 0; k < 6; k++) eq[i * 6 + k] = live ? W.eq[sd][slot][k] : 0.0;
+    }
+    for (int i = t; i < 2 * MAXL * MAXL; i += 256) {
+        const int sd = i / (MAXL * MAXL), pos = (i / MAXL) % MAXL, k = i % MAXL;
+        double x = 0, y = 0;
+        if (pos < W.fin_n[sd]) {
+            const int slot = W.fin_ord[sd][pos];
+            if (k < W.in[sd][slot]) { x = W.ipts[sd][slot][k][0]; y = W.ipts[sd][slot][k][1]; }
+        }
+        pts[2 * i] = x; pts[2 * i + 1] = y;
+    }
+}
+
 }  // namespace
+
+int lines_export(const void *lines_ws, int f, double *eq, int *npts, double *pts, int *n_lines, hipStream_t s)
+{
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_line_tables, dim3(1), dim3(256), 0, s, (const LinesWS *)lines_ws, f, eq, npts, pts, n_lines);
+    CPE_CHECK_LAUNCH("k_line_tables");
+    return CPE_OK;
+}
 
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,

@@ -1094,12 +1094,10 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st,
         // band height by LDS budget: (2 (R + 40) + R) words of 8 bytes per 64 columns
         const int WW = (w + 63) / 64;
         const size_t lds64 = (size_t)(2 * (64 + 2 * OB_AP) + 64) * WW * 8, lds32 = (size_t)(2 * (32 + 2 * OB_AP) + 32) * WW * 8;
-        static bool attr_set = false;
-        if (!attr_set) {   // more than the default 64 KB of dynamic LDS
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_open20_joints<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_open20_joints<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        // more than the default 64 KB of dynamic LDS.  The attribute belongs to the (function, device) pair, so it is set on
+        // every call for the device the launch goes to (cheap, and safe with several GPUs / host threads in one process)
+        CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_open20_joints<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_open20_joints<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (lds64 <= 96 * 1024) {
             const int bands = (h + 63) / 64;
             CPE_KLAUNCH(k_open20_joints<64>, dim3((unsigned)(n * bands)), dim3(256), lds64, s, (const uint8_t *)B.binary, h, w, bands,
@@ -1153,13 +1151,7 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     const int rb_bands = (h + RB_R - 1) / RB_R;
     const size_t rb_lds = (size_t)2 * RB_ROWS * ((w + 63) / 64) * 8;
     CPE_CHECK_ARG(rb_lds <= 160 * 1024, "masks_stage: frame too wide (%d columns)", w);
-    {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roi_base), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-    }
+    CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roi_base), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t bit_words = (size_t)n * h * bit_row_words(w);
     if (side) { (void)hipEventRecord(side->clahe_done, s); (void)hipStreamWaitEvent(side->s, side->clahe_done, 0); }
     for (int which = 0; which < 2; which++) {

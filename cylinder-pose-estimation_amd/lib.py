@@ -34,6 +34,8 @@ _SIGS = {
                               [C.c_void_p] * 6),
     'cpe_detect_grid_batch_ex': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t] +
                                  [C.c_void_p] * 6),
+    'cpe_detect_line_tables': (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
+    'cpe_bgr2gray_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_detect_workspace_plane': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_debug_ccl': (C.c_int32, [C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     'cpe_fit_workspace_bytes': (C.c_size_t, [C.c_int32]),
@@ -65,6 +67,7 @@ class CpeRansacParams(C.Structure):
 
 
 MAXP = 1024
+MAXL = 128
 
 
 def load():

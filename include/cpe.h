@@ -13,7 +13,10 @@
  * Conventions
  *   - extern "C", plain pointers and sizes; every buffer is caller-owned DEVICE memory
  *     (e.g. torch tensors, pass tensor.data_ptr()); no allocation inside, scratch comes from
- *     the caller-supplied workspace; no global state except the thread-local error string.
+ *     the caller-supplied workspace.  Process state: the thread-local error string, the optional profiling timers,
+ *     and per device three helper streams with their events (cpe_detect_grid_batch* overlaps independent chains
+ *     on them; calls on one device are serialised over their enqueue by a per-device mutex, so the library is
+ *     thread-safe; CPE_SERIAL=1 in the environment keeps everything on the caller's stream).
  *   - every call is asynchronous on `stream` (a hipStream_t, passed as void*; NULL = default
  *     stream) and graph-capturable; no host synchronisation inside.
  *   - return value: 0 ok, <0 argument / launch error (text via cpe_last_error_string()).
@@ -109,6 +112,27 @@ typedef struct CpeDetectParams {
 CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
                                          void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
                                          double *center, int32_t *status, void *stream);
+
+/* rows_updated / cols_updated of ONE frame of the last cpe_detect_grid_batch call on this workspace: the third and fourth
+ * return values of detect_grid (python_grid_detection_cylinder.py:110; built by find_and_assign_intersections_P and
+ * clean_and_relabel, util_cylinder.py:1106-1206).  Side 0 = rows ("row1".."rowR", ordered by mean y), side 1 = columns
+ * ("col1".."colC", ordered by mean x; negative columns included -- remove_minus_labels only prunes the JSON).
+ *   eq      f64[2, CPE_MAXL, 6]            [a2, a1, a0, min-50, max+50, span] of the quadratic fit (util_cylinder.py:473-550)
+ *   npts    i32[2, CPE_MAXL]               intersections on the line
+ *   pts     f64[2, CPE_MAXL, CPE_MAXL, 2]  (x, y) in the reference's loop order
+ *   n_lines i32[2]                         R, C  (0, 0 for a frame that failed before this stage)
+ * All device buffers; asynchronous on `stream`. */
+#define CPE_MAXL 128
+CPE_API int32_t cpe_detect_line_tables(const void *ws, size_t ws_bytes, int32_t n, int32_t h, int32_t w, int32_t frame,
+                                       double *eq, int32_t *npts, double *pts, int32_t *n_lines, void *stream);
+
+/* Colour input of the entry point: load_and_preprocess_image converts a 3-channel frame with
+ * cv2.cvtColor(BGR2GRAY) (util_cylinder.py:1781-1789): 8-bit fixed point, gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
+ * ([ext] OpenCV 4.5.5; identity on grey-replicated frames).  bgr u8[n,h,w,3] interleaved -> gray u8[n,h,w]; both
+ * 4-byte aligned device buffers.  The detector then runs on `gray`; the two places where the reference looks at the
+ * colour planes again (LAB L channel of the blob stage, :1840; the 7x7 blur of indexing_data, :1433) see the grey-
+ * replicated image here, which is what a mono laser camera delivers. */
+CPE_API int32_t cpe_bgr2gray_batch(const uint8_t *bgr, int32_t n, int32_t h, int32_t w, uint8_t *gray, void *stream);
 
 /* Where an intermediate of the last cpe_detect_grid_batch call lives inside the workspace (for
  * stage-by-stage parity tests and debugging): plane-major, frame f at offset + f * bytes_per_frame. */

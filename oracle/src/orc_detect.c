@@ -49,6 +49,7 @@ typedef struct {
     int spot[4];      /* out: ellipse cx, cy, a, b */
     int n_rows, n_cols; /* out: lines after clean_and_relabel */
     int n_keypoints;    /* out */
+    orc_lineset *rows_out, *cols_out; /* optional: rows_updated / cols_updated after clean_and_relabel (:2044) */
 } orc_detect_debug;
 
 /* returns status: 0 ok, 1 no region, 2 no spot, 3 no rows/cols, 4 empty */
@@ -143,6 +144,9 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
         dbg->n_rows = (st == 0 || (st >= 3 && st != 7)) ? rows->nlines : 0;
         dbg->n_cols = (st == 0 || (st >= 3 && st != 7)) ? cols->nlines : 0;
         dbg->n_keypoints = nkp;
+        const int have = (st == 0 || (st >= 3 && st != 7));
+        if (dbg->rows_out) { if (have) memcpy(dbg->rows_out, rows, sizeof(orc_lineset)); else dbg->rows_out->nlines = 0; }
+        if (dbg->cols_out) { if (have) memcpy(dbg->cols_out, cols, sizeof(orc_lineset)); else dbg->cols_out->nlines = 0; }
     }
     free(blurred); free(binary); free(hmask); free(vmask); free(mc); free(roi_h); free(roi_v); free(exp_h); free(exp_v);
     free(g7); free(cent); free(cyl); free(rows); free(cols); free(lab_h); free(lab_v); free(crop);

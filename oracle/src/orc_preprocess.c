@@ -188,3 +188,11 @@ ORC_API void orc_preprocess(const uint8_t *gray, int h, int w, uint8_t *blurred,
     free(G);
     if (!b_out) free(b);
 }
+
+/* cv2.cvtColor(img, COLOR_BGR2GRAY) on 8-bit input (load_and_preprocess_image, util_cylinder.py:1781-1789), [ext] OpenCV
+ * 4.5.5 RGB2Gray<uchar>: 15-bit fixed point, coefficients 0.114 / 0.587 / 0.299 -> 3735 / 19235 / 9798 (sum 2^15), rounded */
+ORC_API void orc_bgr2gray(const uint8_t *bgr, size_t npx, uint8_t *gray)
+{
+    for (size_t p = 0; p < npx; p++)
+        gray[p] = (uint8_t)((bgr[3 * p] * 3735u + bgr[3 * p + 1] * 19235u + bgr[3 * p + 2] * 9798u + (1u << 14)) >> 15);
+}

@@ -228,14 +228,34 @@ class DetectDebug(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('binary', 'hmask', 'vmask', 'mask_contour', 'roi_h', 'roi_v', 'exp_h', 'exp_v')] + \
                [('joints', C.c_void_p), ('cap_joints', C.c_int), ('n_joints', C.c_int), ('n_cyl_joints', C.c_int),
                 ('rect', C.c_int * 4), ('r0', C.c_int), ('spot', C.c_int * 4), ('n_rows', C.c_int), ('n_cols', C.c_int),
-                ('n_keypoints', C.c_int)]
+                ('n_keypoints', C.c_int), ('rows_out', C.c_void_p), ('cols_out', C.c_void_p)]
 
 
-def detect_grid(gray, cap=4096, debug=False, subpixel=False, window=7, step=1.0):
-    """detect_grid restated: -> dict(status, center (2,), xy (n,2), id (n,2) [, debug images])"""
+def bgr2gray(bgr):
+    """cv2.cvtColor(BGR2GRAY), 8-bit"""
+    bgr = np.ascontiguousarray(bgr, np.uint8); h, w, c = bgr.shape
+    assert c == 3
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(_p(bgr, C.c_uint8), C.c_size_t(h * w), _p(out, C.c_uint8))
+    return out
+
+
+def line_dict(ls, prefix):
+    """LineSet after clean_and_relabel -> {'points': {'<prefix>1': [(x, y), ..]}, 'equations': {'<prefix>1': [6 floats]}}"""
+    pts = ls.points(); eqs = ls.equations()
+    return {'points': {f'{prefix}{g + 1}': pts[g] for g in range(ls.nlines)},
+            'equations': {f'{prefix}{g + 1}': eqs[g] for g in range(ls.nlines)}}
+
+
+def detect_grid(gray, cap=4096, debug=False, subpixel=False, window=7, step=1.0, lines=False):
+    """detect_grid restated: -> dict(status, center (2,), xy (n,2), id (n,2) [, debug images][, rows / cols: the third and
+    fourth return values of the reference's detect_grid])"""
     gray = _u8(gray); h, w = gray.shape
     center = np.zeros(2); xy = np.zeros((cap, 2)); ids = np.zeros((cap, 2), np.int32); n = C.c_int(0)
     dbg = DetectDebug(); imgs = {}
+    if lines:
+        rows_ls, cols_ls = LineSet(), LineSet()
+        dbg.rows_out = C.addressof(rows_ls); dbg.cols_out = C.addressof(cols_ls)
     if debug:
         for k in ('binary', 'hmask', 'vmask', 'mask_contour', 'roi_h', 'roi_v', 'exp_h', 'exp_v'):
             imgs[k] = np.zeros((h, w), np.uint8)
@@ -250,6 +270,8 @@ def detect_grid(gray, cap=4096, debug=False, subpixel=False, window=7, step=1.0)
     if debug:
         imgs['joints'] = imgs['joints'][:dbg.n_joints].copy()
         out.update(imgs)
+    if lines:
+        out['rows'] = line_dict(rows_ls, 'row'); out['cols'] = line_dict(cols_ls, 'col')
     return out
 
 
