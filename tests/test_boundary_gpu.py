@@ -159,5 +159,5 @@ def test_save_mat_round_trip(cpe, orc, gpu, tmp_path):
         assert np.array_equal(fr[0, i]['cylParams'], out['cyl'][i].cpu().numpy())
         assert np.array_equal(fr[0, i]['cylT'], out['T'][i].cpu().numpy().reshape(4, 4))
         assert np.array_equal(fr[0, i]['fvals'].ravel(), out['fvals'][i].cpu().numpy())
-        assert float(fr[0, i]['meanError']) == float(out['mean_err'][i])
+        assert float(np.ravel(fr[0, i]['meanError'])[0]) == float(out['mean_err'][i])
     assert [str(x[0][0]) for x in m['names']] == ['00', '-1-4']
