@@ -620,6 +620,118 @@ int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t
     return CPE_OK;
 }
 
+
+// ---- RETR_EXTERNAL: which components lie inside a hole of another one ------------------------------------------------
+// cv2.findContours(RETR_EXTERNAL) skips an outer border whose start pixel lies inside the outer border of a component
+// found earlier (icvFindNextContour: the last border mark passed on the row is positive), i.e. every component that sits
+// in a hole of another one, at any depth.  Equivalent, scan-free form: a component is external iff the background pixel
+// west of its raster-first pixel belongs to the OUTER background, the 4-connected background region that reaches the
+// border of the window.  This kernel computes that region as a bit mask, one wavefront per frame:
+//   out[y][j] bit b = 1  <=>  pixel (64 j + b, y) is background and 4-connected to the window border through background
+// by alternating downward / upward sweeps over the rows (lane j owns word j of a row; a row takes what the previous row
+// of the sweep has, fills it sideways through runs of background -- carry-ripple fill inside a word, lane exchange across
+// words) until a sweep changes nothing.  Typical masks (small blobs, open line fragments) converge in two sweeps; the
+// third one only confirms.  Pixels outside the window count as outer background.  w <= 4096 (64 words).
+__device__ __forceinline__ unsigned long long pack_nonzero64(const uint8_t *row, int x0, int w)
+{
+    unsigned long long m = 0;
+    if (x0 + 64 <= w && ((((size_t)row) + x0) & 7) == 0) {
+        const unsigned long long *p = reinterpret_cast<const unsigned long long *>(row + x0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            unsigned long long v = p[k];
+            v |= v >> 4; v |= v >> 2; v |= v >> 1;
+            v &= 0x0101010101010101ull;
+            m |= ((v * 0x0102040810204080ull) >> 56) << (8 * k);
+        }
+    } else {
+        for (int b = 0; b < 64 && x0 + b < w; b++) m |= (unsigned long long)(row[x0 + b] != 0) << b;
+    }
+    return m;
+}
+
+// sideways fill of `seed` through the runs of bg, across the words held by the lanes 0 .. WW-1.
+// Inside a word: adding the seeds to the run mask ripples a carry from every seed to the end of its run (fill towards the
+// high bits); the same on the bit-reversed word fills towards the low bits.  Between words: a filled bit 63 / bit 0 seeds
+// the neighbouring word's bit 0 / bit 63; repeat while any lane received a new seed.
+__device__ __forceinline__ unsigned long long flood_row(unsigned long long bg, unsigned long long seed, int lane, int WW)
+{
+    unsigned long long f = seed & bg;
+    const unsigned long long rb = __brevll(bg);
+    for (;;) {
+        f = (((bg + f) ^ bg) & bg) | f;
+        const unsigned long long rf = __brevll(f);
+        f = __brevll((((rb + rf) ^ rb) & rb) | rf);
+        const unsigned long long from_lo = __shfl_up(f, 1, 64), from_hi = __shfl_down(f, 1, 64);
+        unsigned long long add = 0;
+        if (lane > 0 && lane < WW && (from_lo >> 63) && (bg & 1ull) && !(f & 1ull)) add |= 1ull;
+        if (lane + 1 < WW && (from_hi & 1ull) && (bg >> 63) && !(f >> 63)) add |= 1ull << 63;
+        if (!__ballot(add != 0ull)) break;
+        f |= add;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict__ mask, int h, int w, const FrameState *__restrict__ st,
+                                                      int use_rect, unsigned long long *__restrict__ bgw_all,
+                                                      unsigned long long *__restrict__ out_all, size_t plane_words)
+{
+    const size_t f = blockIdx.x;
+    const int lane = threadIdx.x, WW = (w + 63) >> 6;
+    const Rect r = get_rect(st, f, use_rect, h, w);
+    if (r.x1 < r.x0 || r.y1 < r.y0) return;
+    const uint8_t *im = mask + f * (size_t)h * w;
+    unsigned long long *bgw = bgw_all + f * plane_words, *out = out_all + f * plane_words;
+    const int x0 = lane * 64;
+    const unsigned long long cmask = lane < WW ? col_mask64(x0, r.x0, r.x1) : 0ull;
+    // window columns x0r / x1r touch the outside on their left / right
+    unsigned long long edge = 0;
+    if (lane < WW) {
+        if (r.x0 >= x0 && r.x0 < x0 + 64) edge |= 1ull << (r.x0 - x0);
+        if (r.x1 >= x0 && r.x1 < x0 + 64) edge |= 1ull << (r.x1 - x0);
+    }
+    // sweep 0 (down): pack the background once, seed from the window border
+    unsigned long long prev = ~0ull;   // the row above the window is all outside
+    for (int y = r.y0; y <= r.y1; y++) {
+        unsigned long long bg = 0;
+        if (lane < WW) bg = ~pack_nonzero64(im + (size_t)y * w, x0, w) & cmask;
+        unsigned long long seed = (prev | edge) & bg;
+        if (y == r.y1) seed = bg;      // the row below the window is all outside
+        const unsigned long long o = flood_row(bg, seed, lane, WW);
+        if (lane < WW) { bgw[(size_t)y * WW + lane] = bg; out[(size_t)y * WW + lane] = o; }
+        prev = o;
+    }
+    // further sweeps, alternating direction, until nothing changes (this wavefront's own stores: visible to it in order)
+    for (int pass = 1; pass < 4096; pass++) {
+        const bool upw = pass & 1;
+        bool any = false;
+        prev = ~0ull;
+        for (int k = r.y0; k <= r.y1; k++) {
+            const int y = upw ? r.y1 - (k - r.y0) : k;
+            unsigned long long bg = 0, cur = 0;
+            if (lane < WW) { bg = bgw[(size_t)y * WW + lane]; cur = out[(size_t)y * WW + lane]; }
+            const unsigned long long seed = cur | (prev & bg);
+            unsigned long long o = cur;
+            if (__ballot(seed != cur)) {
+                o = flood_row(bg, seed, lane, WW);
+                if (lane < WW && o != cur) { out[(size_t)y * WW + lane] = o; any = true; }
+            }
+            prev = o;
+        }
+        if (!__ballot(any)) break;
+    }
+}
+
+int outside_flood(const uint8_t *mask, int n, int h, int w, const FrameState *st, int use_rect, unsigned long long *bgw,
+                  unsigned long long *out, size_t plane_words, hipStream_t s)
+{
+    CPE_CHECK_ARG(w <= 4096 && plane_words >= (size_t)h * ((w + 63) >> 6), "outside_flood: frame too wide or scratch too small");
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_outside_flood, dim3(n), dim3(64), 0, s, mask, h, w, st, use_rect, bgw, out, plane_words);
+    CPE_CHECK_LAUNCH("k_outside_flood");
+    return CPE_OK;
+}
+
 // One labelling pass.  roots (optional): component list in st[].n_roots / roots; holes_only drops components
 // that reach the border of the working rectangle (needs `touch`); count_mode/cnt as in k_ccl_finish;
 // count_mode 3 only zeroes cnt inside the set's rectangle; sparse 1: labels of pixels outside the set are left untouched,

@@ -120,6 +120,25 @@ __device__ __forceinline__ int *root_counter(FrameState &S, int sel)
     return sel == 0 ? &S.n_roots : (sel == 1 ? &S.n_roots_p : &S.n_roots_s);
 }
 
+// ---------------------------------------------------------------- RETR_EXTERNAL (ccl.hip: k_outside_flood)
+// outer-background mask of every frame's window (use_rect 0: the frame, 2: region rectangle + 2 px): out[f][y][j] bit b = pixel
+// (64 j + b, y) is background and 4-connected to the window border.  bgw / out: n * plane_words u64 of scratch each,
+// plane_words >= h * ceil(w / 64).
+int outside_flood(const uint8_t *mask, int n, int h, int w, const FrameState *st, int use_rect, unsigned long long *bgw,
+                  unsigned long long *out, size_t plane_words, hipStream_t s);
+// a component (raster-first pixel `root`) is external iff the pixel west of that pixel is outer background
+// (cv2.findContours(RETR_EXTERNAL) drops the components that lie in a hole of another one)
+__device__ __forceinline__ bool comp_is_external(const unsigned long long *out_f, int w, int root, int win_x0)
+{
+    const int y = root / w, x = root - y * w;
+    if (x - 1 < win_x0) return true;          // the window border / the image border is outer background
+    return (out_f[(size_t)y * ((w + 63) >> 6) + ((x - 1) >> 6)] >> ((x - 1) & 63)) & 1ull;
+}
+__device__ __forceinline__ int window_x0(const FrameState &S, int use_rect)
+{
+    return use_rect == 2 ? max(S.rect[0] - 2, 0) : (use_rect == 1 ? S.crect[0] : 0);
+}
+
 // ---------------------------------------------------------------- union-find on an int label plane
 __device__ __forceinline__ int uf_load(const int *L, int i)
 {

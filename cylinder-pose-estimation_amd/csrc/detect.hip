@@ -340,6 +340,49 @@ extern "C" int32_t cpe_bgr2gray_batch(const uint8_t *bgr, int32_t n, int32_t h, 
     return CPE_OK;
 }
 
+// cv2.findContours(mask, RETR_EXTERNAL, .) reduced to what its callers keep of the hierarchy: the raster-first pixels of the
+// components that do NOT lie inside a hole of another component (tests of the RETR_EXTERNAL rule, util_cylinder.py:161,1817)
+namespace cpe { namespace {
+__global__ __launch_bounds__(256) void k_list_external(const int *__restrict__ roots, const FrameState *__restrict__ st, int w,
+                                                       const unsigned long long *__restrict__ outside, size_t plane_words,
+                                                       int *__restrict__ first_px, int cap, int *__restrict__ count)
+{
+    const int f = blockIdx.y;
+    const int ncomp = min(st[f].n_roots, MAXROOTS);
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < ncomp; k += gridDim.x * 256) {
+        const int root = roots[(size_t)f * MAXROOTS + k];
+        if (!comp_is_external(outside + f * plane_words, w, root, 0)) continue;
+        const int q = atomicAdd(&count[f], 1);
+        if (q < cap) first_px[(size_t)f * cap + q] = root;
+    }
+}
+} }
+
+extern "C" int32_t cpe_debug_external_components(const uint8_t *mask, int32_t n, int32_t h, int32_t w, void *ws, size_t ws_bytes,
+                                                 int32_t *first_px, int32_t cap, int32_t *count, void *stream)
+{
+    CPE_CHECK_ARG(mask && ws && first_px && count && n > 0 && h >= 64 && w >= 64 && w <= 4096 && cap > 0, "cpe_debug_external_components: bad argument");
+    Layout L = make_layout(n, h, w);
+    CPE_CHECK_ARG(ws_bytes >= L.total && ((uintptr_t)ws & 255) == 0, "cpe_debug_external_components: workspace too small or misaligned");
+    uint8_t *base = (uint8_t *)ws;
+    hipStream_t s = (hipStream_t)stream;
+    FrameState *st = (FrameState *)(base + L.off[P_STATE]);
+    int *roots = (int *)(base + L.off[P_ROOTS]);
+    int rc;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    CPE_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)n * sizeof(int), s));
+    if ((rc = ccl_run(mask, n, h, w, 0, 0, 1, (int *)(base + L.off[P_LAB0]), roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 0)) != CPE_OK) return rc;
+    const size_t bit_words = (size_t)n * h * bit_row_words(w), fl_words = (size_t)h * bit_row_words(w) / 2;
+    unsigned long long *bgw = (unsigned long long *)(base + L.off[P_BITS]);
+    unsigned long long *out = (unsigned long long *)((uint32_t *)(base + L.off[P_BITS]) + ((bit_words + 1) & ~(size_t)1));
+    if ((rc = outside_flood(mask, n, h, w, st, 0, bgw, out, fl_words, s)) != CPE_OK) return rc;
+    CPE_KLAUNCH(k_list_external, dim3(32, n), dim3(256), 0, s, (const int *)roots, (const FrameState *)st, w, (const unsigned long long *)out, fl_words,
+                first_px, cap, count);
+    CPE_CHECK_LAUNCH("k_list_external");
+    return CPE_OK;
+}
+
 // Stand-alone labelling pass over the workspace's label planes (profiling / tests): labels of
 // {(img > thr) != invert} land in the CPE_PLANE_LABELS plane.
 extern "C" int32_t cpe_debug_ccl(const uint8_t *img, int32_t n, int32_t h, int32_t w, int32_t thr, int32_t invert,

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m,
 // ---- joints: polygon-moment centroids inside the region rectangle, in cv2.findContours order ----------
 __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restrict__ jm, int h, int w,
                                                         const int *__restrict__ roots, FrameState *__restrict__ st,
-                                                        int *__restrict__ jtmp /* n*MAXJ*3 */)
+                                                        int *__restrict__ jtmp /* n*MAXJ*3 */,
+                                                        const unsigned long long *__restrict__ outside, size_t plane_words)
 {
     const int f = blockIdx.y;
     if (st[f].status != CPE_ST_OK) return;
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restric
     const int ncomp = min(st[f].n_roots_p, MAXROOTS);
     for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {
         const int root = roots[(size_t)f * MAXROOTS + k];
+        if (!comp_is_external(outside + f * plane_words, w, root, 0)) continue;   // RETR_EXTERNAL (:1817): inside a hole of another blob
         MaskPred nz{jm + f * N, w, h};
         StatVisitor sv;
         if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { set_overflow(st[f], OVF_TRACE); continue; }
@@ -866,7 +868,8 @@ constexpr int SEG_LPW = 4;
 template <int MINV, int MAXVS>
 __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ base_bits, int h, int w, int which,
                                                   const int *__restrict__ roots, int cnt_sel, FrameState *__restrict__ st,
-                                                  SegRec *__restrict__ segs /* n*MAXSEG */)
+                                                  SegRec *__restrict__ segs /* n*MAXSEG */,
+                                                  const unsigned long long *__restrict__ outside, size_t plane_words)
 {
     const int f = blockIdx.y;
     if (st[f].status != CPE_ST_OK) return;
@@ -878,6 +881,7 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     if (threadIdx.x >= SEG_LPW) return;
     for (int k = blockIdx.x * SEG_LPW + threadIdx.x; k < ncomp; k += gridDim.x * SEG_LPW) {
     const int root = roots[(size_t)f * MAXROOTS + k];
+    if (!comp_is_external(outside + f * plane_words, w, root, window_x0(st[f], 2))) continue;   // RETR_EXTERNAL (:161)
     const int ws = bit_row_words(w);
     BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
     float pts[2 * MAXVS];
@@ -1143,8 +1147,15 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     int rc;
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_masks_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    // scratch of the RETR_EXTERNAL tests: u64 planes carved from the one-bit planes the region stage is done with
+    // (planes 0 and 1 hold the fragment masks below; a u64 plane of h * ceil(w/64) words fits one bit plane)
+    const size_t bit_words = (size_t)n * h * bit_row_words(w);
+    const size_t fl_words = (size_t)h * bit_row_words(w) / 2;          // u64 words per frame of one flood plane
+    auto fl_plane = [&](int k) { return reinterpret_cast<unsigned long long *>(B.bits + (size_t)(2 + k) * ((bit_words + 1) & ~(size_t)1)); };
     // joints
-    CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp);
+    if ((rc = outside_flood(B.joints_mask, n, h, w, st, 0, fl_plane(0), fl_plane(1), fl_words, s)) != CPE_OK) return rc;
+    CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp,
+                (const unsigned long long *)fl_plane(1), fl_words);
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // a-5 tail, a-6 and the labelling of the expanded masks, once per line direction.  The two directions share
     // nothing but their inputs: the vertical one runs on the helper stream (if any) with the spot chain's label plane.
@@ -1152,7 +1163,6 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     const size_t rb_lds = (size_t)2 * RB_ROWS * ((w + 63) / 64) * 8;
     CPE_CHECK_ARG(rb_lds <= 160 * 1024, "masks_stage: frame too wide (%d columns)", w);
     CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roi_base), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const size_t bit_words = (size_t)n * h * bit_row_words(w);
     if (side) { (void)hipEventRecord(side->clahe_done, s); (void)hipStreamWaitEvent(side->s, side->clahe_done, 0); }
     for (int which = 0; which < 2; which++) {
         hipStream_t q = (which && side) ? side->s : s;
@@ -1170,8 +1180,10 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
                     h, w, rb_bands, (const FrameState *)st, roi, base);
         if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
-        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
-        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs);
+        unsigned long long *fl_bg = fl_plane(2 + 2 * which), *fl_out = fl_plane(3 + 2 * which);
+        if ((rc = outside_flood(base, n, h, w, st, 2, fl_bg, fl_out, fl_words, q)) != CPE_OK) return rc;
+        if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs, (const unsigned long long *)fl_out, fl_words);
+        else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs, (const unsigned long long *)fl_out, fl_words);
         CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, q, st, which, (const SegRec *)segs);
         (void)hipMemsetAsync(tmp, 0, total, q);
         if (planar) CPE_KLAUNCH(k_seg_expand<EXP_MAXKS_PLANE>, dim3(frame_waves(n, 32, 256), n), dim3(256), 0, q, (const uint8_t *)base, h, w, which, st, (const SegRec *)segs, tmp, 201);

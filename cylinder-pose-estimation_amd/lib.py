@@ -37,6 +37,8 @@ _SIGS = {
     'cpe_detect_line_tables': (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     'cpe_bgr2gray_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_detect_workspace_plane': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'cpe_debug_external_components': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_void_p]),
     'cpe_debug_ccl': (C.c_int32, [C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     'cpe_fit_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'cpe_select_triangulate_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 +

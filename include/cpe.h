@@ -163,6 +163,13 @@ CPE_API int32_t cpe_debug_ccl(const uint8_t *img, int32_t n, int32_t h, int32_t 
                               int32_t conn8, int32_t count_mode, int32_t want_bbox, int32_t want_roots, void *ws,
                               size_t ws_bytes, void *stream);
 
+/* The RETR_EXTERNAL rule of cv2.findContours as the detector applies it (util_cylinder.py:161, 1817; the other two call
+ * sites, :1883 and :1968, keep only the largest contour, which is never a nested one): of the 8-connected components of
+ * mask != 0, the raster-first pixels (y * w + x, any order) of those that do not lie inside a hole of another component.
+ * first_px i32[n,cap], count i32[n] (may exceed cap: then only cap entries were stored).  Test / debugging aid. */
+CPE_API int32_t cpe_debug_external_components(const uint8_t *mask, int32_t n, int32_t h, int32_t w, void *ws, size_t ws_bytes,
+                                              int32_t *first_px, int32_t cap, int32_t *count, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grid-point tables.  One table per image: xy f64[n,CPE_MAXP,2] pixel coordinates, id i32[n,CPE_MAXP,2]
  * (col,row) grid indices, cnt i32[n] -- the padded form of the reference's N x 4 matrix
