@@ -21,6 +21,11 @@
 namespace {
 
 constexpr int MAXP = CPE_MAXP;
+// the per-point LDS arrays of the one-wavefront-per-frame kernels (dynamic: they exceed the static 64 KB limit)
+extern __shared__ double fit_dyn[];
+constexpr size_t SEL_LDS_BYTES = (size_t)MAXP * (3 * 8 + 8 + 8 + 4 + 4 + 1);
+constexpr size_t FIT_LDS_BYTES = (size_t)MAXP * 4 * 8;
+constexpr size_t RANSAC_LDS_BYTES = (size_t)MAXP * 7 * 8;
 constexpr int TBL = CPE_FIT_TABLE_DIM;  // dense (col,row) table is TBL x TBL per image
 constexpr int MAXU = TBL;
 
@@ -178,14 +183,15 @@ __global__ __launch_bounds__(64) void k_select_triangulate(
     double *__restrict__ o_X, double *__restrict__ o_err, int *__restrict__ o_m,
     double *__restrict__ o_mean_err, int *__restrict__ o_flags)
 {
-    __shared__ double sX[MAXP * 3];
-    __shared__ double sErr[MAXP];
-    __shared__ int sJ[MAXP];            // matching slot in image 2 (or -1)
-    __shared__ unsigned char sSel[MAXP];
+    // per-point arrays: dynamic LDS (SEL_LDS_BYTES; more than the 64 KB a kernel may declare statically)
+    double *sX = fit_dyn;                                                                   // [MAXP * 3]
+    double *sErr = sX + MAXP * 3;                                                           // [MAXP]
+    unsigned long long *sKey = reinterpret_cast<unsigned long long *>(sErr + MAXP);         // [MAXP]
+    int *sJ = reinterpret_cast<int *>(sKey + MAXP);                                         // [MAXP] matching slot in image 2 (or -1)
+    int *sOrder = sJ + MAXP;                                                                // [MAXP] output position -> gp1 slot
+    unsigned char *sSel = reinterpret_cast<unsigned char *>(sOrder + MAXP);                 // [MAXP]
     __shared__ int sUx[MAXU], sUy[MAXU];
     __shared__ unsigned char sFx[MAXU], sFy[MAXU];
-    __shared__ unsigned long long sKey[MAXP];
-    __shared__ int sOrder[MAXP];        // output position -> gp1 slot
     const int f = blockIdx.x, lane = threadIdx.x;
     const double *a1 = xy1 + (size_t)f * MAXP * 2, *a2 = xy2 + (size_t)f * MAXP * 2;
     const int *i1 = id1 + (size_t)f * MAXP * 2, *i2 = id2 + (size_t)f * MAXP * 2;
@@ -906,8 +912,7 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
                                                      double *__restrict__ o_fvals, int *__restrict__ o_iters,
                                                      int *__restrict__ o_status)
 {
-    __shared__ double sP[MAXP * 3];
-    __shared__ double sD[MAXP];
+    double *sP = fit_dyn, *sD = fit_dyn + MAXP * 3;   // dynamic LDS, FIT_LDS_BYTES
     __shared__ int sNb[20];
     const int f = blockIdx.x, lane = threadIdx.x;
     const int n = min(max(cnt[f], 0), MAXP);
@@ -956,8 +961,7 @@ __global__ __launch_bounds__(64) void k_fit_ransac(const double *__restrict__ X,
                                                    double *__restrict__ o_fvals, int *__restrict__ o_iters, int *__restrict__ o_status,
                                                    int *__restrict__ o_ninl, uint8_t *__restrict__ o_mask)
 {
-    __shared__ double sP[MAXP * 3], sQ[MAXP * 3];
-    __shared__ double sD[MAXP];
+    double *sP = fit_dyn, *sQ = fit_dyn + MAXP * 3, *sD = fit_dyn + MAXP * 6;   // dynamic LDS, RANSAC_LDS_BYTES
     __shared__ int sNb[20];
     const int f = blockIdx.x, lane = threadIdx.x;
     const int n = min(max(cnt[f], 0), MAXP);
@@ -1059,7 +1063,8 @@ extern "C" int32_t cpe_select_triangulate_batch(const double *xy1, const int32_t
         return CPE_ERR_WORKSPACE;
     }
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_select_triangulate, dim3(n), dim3(64), 0, (hipStream_t)stream, xy1, id1, cnt1, xy2, id2, cnt2,
+    CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select_triangulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEL_LDS_BYTES));
+    CPE_KLAUNCH(k_select_triangulate, dim3(n), dim3(64), SEL_LDS_BYTES, (hipStream_t)stream, xy1, id1, cnt1, xy2, id2, cnt2,
                        K1, K2, T21, selector, patch, th, (int *)ws, p1, p2, idx, X, err, m, mean_err, flags);
     CPE_CHECK_LAUNCH("k_select_triangulate");
     return CPE_OK;
@@ -1078,11 +1083,13 @@ extern "C" int32_t cpe_fit_cylinder_batch(const double *X, const int32_t *cnt, i
     if (n == 0) return CPE_OK;
     CPE_LAUNCH_BEGIN();
     CPE_CHECK_ARG(p.mode == CPE_FIT_NELDER_MEAD || p.mode == CPE_FIT_LM, "cpe_fit_cylinder_batch: unknown mode %d", p.mode);
+    CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_cylinder<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIT_LDS_BYTES));
+    CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_cylinder<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FIT_LDS_BYTES));
     if (p.mode == CPE_FIT_LM)
-        CPE_KLAUNCH(k_fit_cylinder<1>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
+        CPE_KLAUNCH(k_fit_cylinder<1>, dim3(n), dim3(64), FIT_LDS_BYTES, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
                     p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
     else
-        CPE_KLAUNCH(k_fit_cylinder<0>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
+        CPE_KLAUNCH(k_fit_cylinder<0>, dim3(n), dim3(64), FIT_LDS_BYTES, (hipStream_t)stream, X, cnt, radius, p.tol_x, p.tol_f, p.max_iter,
                     p.max_fun_evals, cyl_raw, cyl, T, fvals, iters, status);
     CPE_CHECK_LAUNCH("k_fit_cylinder");
     return CPE_OK;
@@ -1106,12 +1113,14 @@ extern "C" int32_t cpe_fit_cylinder_ransac_batch(const double *X, const int32_t 
                   "cpe_fit_cylinder_ransac_batch: bad CpeRansacParams (hypotheses 1..4096, sample >= 6, tau > 0, hyp_iters >= 1)");
     if (n == 0) return CPE_OK;
     CPE_LAUNCH_BEGIN();
+    CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_ransac<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANSAC_LDS_BYTES));
+    CPE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_ransac<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANSAC_LDS_BYTES));
     if (p.mode == CPE_FIT_LM)
-        CPE_KLAUNCH(k_fit_ransac<1>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, r.hypotheses, r.sample, r.tau,
+        CPE_KLAUNCH(k_fit_ransac<1>, dim3(n), dim3(64), RANSAC_LDS_BYTES, (hipStream_t)stream, X, cnt, radius, r.hypotheses, r.sample, r.tau,
                     (unsigned long long)r.seed, (unsigned long long)r.frame0, r.hyp_iters, p.tol_x, p.tol_f, p.max_iter, p.max_fun_evals,
                     cyl_raw, cyl, T, fvals, iters, status, n_inliers, inlier_mask);
     else
-        CPE_KLAUNCH(k_fit_ransac<0>, dim3(n), dim3(64), 0, (hipStream_t)stream, X, cnt, radius, r.hypotheses, r.sample, r.tau,
+        CPE_KLAUNCH(k_fit_ransac<0>, dim3(n), dim3(64), RANSAC_LDS_BYTES, (hipStream_t)stream, X, cnt, radius, r.hypotheses, r.sample, r.tau,
                     (unsigned long long)r.seed, (unsigned long long)r.frame0, r.hyp_iters, p.tol_x, p.tol_f, p.max_iter, p.max_fun_evals,
                     cyl_raw, cyl, T, fvals, iters, status, n_inliers, inlier_mask);
     CPE_CHECK_LAUNCH("k_fit_ransac");

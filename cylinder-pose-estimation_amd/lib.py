@@ -68,7 +68,7 @@ class CpeRansacParams(C.Structure):
                 ('frame0', C.c_uint64), ('hyp_iters', C.c_int32), ('reserved', C.c_int32)]
 
 
-MAXP = 1024
+MAXP = 2048
 MAXL = 128
 
 

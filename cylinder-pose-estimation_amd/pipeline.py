@@ -12,16 +12,16 @@ REC = 16   # f64 per frame: cyl0[6] | cyl[6] (both after applyCylParamsPrior) | 
 
 
 def pack_counters(n_pts, iters, fit_status, det_l, det_r):
-    """n_pts (<2048), iterations (<2^20), statuses -> one exactly representable double"""
-    code = n_pts.to(torch.int64) + 2048 * (iters.to(torch.int64) + (1 << 20) * (fit_status.to(torch.int64) * 64 +
+    """n_pts (<4096), iterations (<2^20), statuses -> one exactly representable double"""
+    code = n_pts.to(torch.int64) + 4096 * (iters.to(torch.int64) + (1 << 20) * (fit_status.to(torch.int64) * 64 +
                                                                                  det_l.to(torch.int64) * 8 + det_r.to(torch.int64)))
     return code.to(torch.float64)
 
 
 def unpack_counters(code):
     code = code.to(torch.int64)
-    n_pts = code % 2048
-    rest = code // 2048
+    n_pts = code % 4096
+    rest = code // 4096
     iters = rest % (1 << 20)
     st = rest // (1 << 20)
     return n_pts, iters, st // 64, (st // 8) % 8, st % 8

@@ -175,7 +175,7 @@ CPE_API int32_t cpe_debug_external_components(const uint8_t *mask, int32_t n, in
  * (col,row) grid indices, cnt i32[n] -- the padded form of the reference's N x 4 matrix
  * [x y colIdx rowIdx] (makePyGridPts.m:39-41, pointsStruct2mat.m:16).
  */
-#define CPE_MAXP 1024          /* capacity of one grid-point table */
+#define CPE_MAXP 2048          /* capacity of one grid-point table (a 3840x2160 frame holds ~1000-1400 points) */
 #define CPE_FIT_TABLE_DIM 128  /* (col,row) indices of one frame must span < 128 in each direction */
 
 #define CPE_FIT_FLAG_FALLBACK 1 /* selector found nothing -> plain index join (chooseIdx.m:101-104) */

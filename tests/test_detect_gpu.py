@@ -239,3 +239,36 @@ def test_full_size_batch_invariance(cpe, orc, gpu):
     assert torch.equal(one[0], ref[7])
     n_pts, iters, fit_st, dl, dr = pipeline.unpack_counters(ref[:, 15])
     assert int(((fit_st == 0) & (dl == 0) & (dr == 0)).sum()) >= F - 2       # the synthetic frames are detectable
+
+
+def _paint_lens(g, xc, yc, L, a, dash):
+    """two thin bright arcs that meet at both ends (a lens) with a short bright dash in the middle: after the 20x1 opening
+    and the 3x3 open / close the lens is ONE line fragment with a hole and the dash is a fragment INSIDE that hole"""
+    yy, xx = np.mgrid[:g.shape[0], :g.shape[1]].astype(np.float32)
+    t = (xx - xc) / L
+    for sgn in (-1, 1):
+        d = np.abs(yy - (yc + sgn * a * (1 - t * t)))
+        g += np.where(np.abs(t) <= 1, 210 * np.exp(-0.5 * (d / 1.6) ** 2), 0)
+    g += np.where(np.abs(xx - xc) <= dash, 210 * np.exp(-0.5 * (np.abs(yy - yc) / 1.6) ** 2), 0)
+    return g
+
+
+@pytest.mark.gpu
+def test_fragment_inside_a_hole_of_another_is_dropped(cpe, orc, gpu):
+    """RETR_EXTERNAL at expand_line_roi (util_cylinder.py:161): a line fragment that lies in a hole of another fragment is not
+    a contour for the reference, so it is neither measured nor expanded.  The frame really contains such a fragment (checked on
+    the oracle's masks), and the GPU agrees with the oracle on every stage."""
+    from cpe_amd import synth
+    from oracle import stages as S
+    b = synth.render_batch(1, 1200, 1920, seed=5, with_gt=False)
+    r = S.detect_grid(b['left'][0].numpy())
+    x0, y0, rw, rh = r['rect']
+    g = _paint_lens(b['left'][0].numpy().astype(np.float32), x0 + rw // 4, y0 + rh // 3 + 17, 70, 9, 18)
+    img = np.clip(np.round(g), 0, 255).astype(np.uint8)
+    ref = S.detect_grid(img, debug=True)
+    base = S.close_rect(ref['roi_h'], 3, 3)
+    n_all = sum(1 for p, hole in S.find_contours(base, 'list', 'simple') if not hole)
+    n_ext = len(S.find_contours(base, 'external', 'simple'))
+    assert n_ext < n_all                                    # the nesting exists at this call site
+    n_ok = _compare(cpe, orc, gpu, torch.from_numpy(np.stack([img, b['right'][0].numpy()])))
+    assert n_ok == 2
