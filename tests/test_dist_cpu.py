@@ -55,7 +55,7 @@ def test_pack_counters_roundtrip():
     sys.path.insert(0, ROOT)
     import cpe_amd
     from cpe_amd import pipeline as P
-    n = torch.tensor([0, 180, 1024]); it = torch.tensor([1, 283, 99999]); fs = torch.tensor([0, 5, 0])
+    n = torch.tensor([0, 180, 2048]); it = torch.tensor([1, 283, 99999]); fs = torch.tensor([0, 5, 0])
     dl = torch.tensor([0, 2, 6]); dr = torch.tensor([1, 0, 3])
     got = P.unpack_counters(P.pack_counters(n, it, fs, dl, dr))
     for a, b in zip(got, (n, it, fs, dl, dr)):

@@ -28,7 +28,7 @@ def test_ransac_matches_oracle_and_rejects_outliers(cpe, orc, gpu, mode):
     rng = np.random.default_rng(5)
     cases = [(260, 0), (240, 30), (200, 50), (90, 10), (5, 0), (2, 0)]
     n = len(cases)
-    X = np.zeros((n, 1024, 3)); cnt = np.zeros(n, np.int32); axes = []
+    X = np.zeros((n, cpe.fit.MAXP, 3)); cnt = np.zeros(n, np.int32); axes = []
     for i, (m, no) in enumerate(cases):
         P, ax = _cyl_points(rng, max(m, 1), n_out=no)
         X[i, :m] = P[:m]; cnt[i] = m; axes.append(ax)

@@ -19,6 +19,10 @@ def bits(v):
     return '|'.join(n for k, n in enumerate(OVF) if v >> k & 1) or '-'
 
 
+saved = [0]
+save_dir = os.environ.get('CENSUS_SAVE')
+
+
 def run(frames, tag, chunk=16):
     dev = torch.device('cuda:0')
     n = frames.shape[0]
@@ -38,6 +42,10 @@ def run(frames, tag, chunk=16):
                     f'seg {d["n_seg0"]},{d["n_seg1"]} dark max {sw[i, 8:25].max()} bright max {sw[i, 25:42].max()} blobs max {sw[i, 42:59].max()}')
             if s == 6 or (i0 + i) < 2:
                 print(line)
+            if s == 6 and save_dir and saved[0] < 3:
+                os.makedirs(save_dir, exist_ok=True)
+                np.save(os.path.join(save_dir, f'ovf_{tag.split()[0]}_{i0 + i}.npy'), frames[i0 + i].numpy())
+                saved[0] += 1
     print(tag, 'status histogram', dict(sorted(hist.items())))
 
 
