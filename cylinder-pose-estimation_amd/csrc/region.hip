@@ -1108,6 +1108,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     W.bh = B.swbh; W.bcap = sw_tiles_x(w) * sw_tiles_y(h);
     W.hb_off = B.hboff; W.hb_ent = reinterpret_cast<int2 *>(B.hpar); W.hb_cap = (int)(N / 2);
     W.hl = B.hl; W.bl = B.bl; W.tl = B.tl;
+    { const char *e = getenv("CPE_SW_DBG"); W.dbg = e ? atoi(e) : 0; }
     // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count), B.tl[k] = the
     // ones whose border is followed
     if ((rc = sweep_dark(W, n, h, w, st, s)) != CPE_OK) return rc;

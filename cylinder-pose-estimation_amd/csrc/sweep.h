@@ -39,6 +39,7 @@ struct SweepBuffers {
     int2 *bh; int bcap;           // batch headers [n][2][NTHR][bcap]: (first pool entry, entries)
     int *hb_off;                  // holes binned by the tile of their west pixel: offsets [n][tiles + 1] (+ cursors [n][tiles])
     int2 *hb_ent; int hb_cap;     // ... entries (west pixel inside its tile | threshold << 12, pixels of the hole)
+    int dbg;                      // timing aid (CPE_SW_DBG): stop the tile pass early
     int2 *hl, *bl, *tl;           // results [n][NTHR][sweep_cap]: holes / bright components / holes whose border is followed
 };
 
