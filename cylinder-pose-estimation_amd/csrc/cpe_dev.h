@@ -71,11 +71,9 @@ struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };
 // stage buffer bundles (all device pointers into the caller's workspace, plane-major [n][...])
 struct RegionBuffers {
     uint8_t *cl, *ext, *mc, *touch;
-    int *lab, *cnt, *roots, *sw, *nrect;
-    int *bk;                   // event pool of the threshold sweep (h * w / 2 int2 entries per frame)
-    int *hpar;                 // holes binned by tile for the bright pass (h * w / 2 int2 entries per frame)
-    int2 *swbh; int *hboff;    // sweep: batch headers [n][2][17][tiles], hole-bin offsets [n][2 tiles + 2]
+    int *lab, *cnt, *lab2, *cnt2, *roots, *sw, *nrect, *bk;
     double *gmid;              // middle centres (x, y, r) of the blob groups beyond MAXG_LDS
+    int *hpar; uint8_t *htime;   // merge history of the bright forest: (absorbing root, step) per absorbed entry
     uint32_t *pool;   // border points of the hole traces (chunked)
     unsigned short *blob_ch;   // first 16 chunk ids of every blob's border
     int maxch, maxdf;          // capacities per frame and threshold: border-point chunks, distance scratch (doubles)

@@ -7,7 +7,7 @@
 // Everything stays in HBM between the u8 frame read and the point-table write; all scratch lives in the
 // caller-supplied workspace (cpe_detect_workspace_bytes), laid out plane-major so that every kernel
 // streams [n, h, w] planes with fully coalesced accesses.
-#include "sweep.h"
+#include "cpe_dev.h"
 #include <mutex>
 #include <stdlib.h>
 #include <algorithm>
@@ -43,7 +43,7 @@ struct Layout {
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_HPAR, P_SWBH, P_HBOFF, P_GMID, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_HPAR, P_HTIME, P_GMID, P_COUNT
 };
 
 static_assert(P_COUNT <= 64, "Layout arrays too small");
@@ -81,17 +81,18 @@ Layout make_layout(int n, int h, int w)
     per[P_HULL] = (size_t)4 * w * sizeof(int);
     per[P_LINES] = lines_ws_bytes();
     per[P_NRECT] = 16 * sizeof(int);
-    per[P_SW] = SW_STRIDE * sizeof(int);
+    per[P_LAB2] = N * 4;
+    per[P_LAB3] = N * 4;
+    per[P_SW] = 192 * sizeof(int);
     per[P_TL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
-    per[P_BK] = N * 4;          // event pool of the sweep: N / 2 int2 entries
+    per[P_BK] = N * 4;
     per[P_LABP] = N * 4;
     per[P_LABS] = N * 4;
     per[P_ROOTSP] = (size_t)MAXROOTS * sizeof(int);
     per[P_ROOTSS] = (size_t)MAXROOTS * sizeof(int);
     per[P_BEST2] = sizeof(unsigned long long);
-    per[P_HPAR] = N * 4;        // holes binned by tile (bright pass of the sweep): N / 2 int2 entries
-    per[P_SWBH] = (size_t)2 * NTHR * sw_tiles_x(w) * sw_tiles_y(h) * sizeof(int2);
-    per[P_HBOFF] = (size_t)(2 * sw_tiles_x(w) * sw_tiles_y(h) + 2) * sizeof(int);
+    per[P_HPAR] = N * 4;
+    per[P_HTIME] = N;
     per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 3 * sizeof(double);
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);
     per[P_HL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
@@ -218,8 +219,8 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     FrameState *st = PL(FrameState, P_STATE);
     RegionBuffers R;
     R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
-    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.swbh = PL(int2, P_SWBH); R.hboff = PL(int, P_HBOFF);
-    R.sw = PL(int, P_SW); R.hl = PL(int2, P_HL); R.bl = PL(int2, P_BL); R.tl = PL(int2, P_TL); R.bk = PL(int, P_BK); R.bits = PL(uint32_t, P_BITS); R.pool = PL(uint32_t, P_POOL); R.blob_ch = PL(unsigned short, P_BLOB_CH); R.maxch = region_maxch(h, w); R.maxdf = region_maxdf(h, w); R.gmid = PL(double, P_GMID); R.hpar = PL(int, P_HPAR); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
+    R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.lab2 = PL(int, P_LAB2); R.cnt2 = PL(int, P_LAB3);
+    R.sw = PL(int, P_SW); R.hl = PL(int2, P_HL); R.bl = PL(int2, P_BL); R.tl = PL(int2, P_TL); R.bk = PL(int, P_BK); R.bits = PL(uint32_t, P_BITS); R.pool = PL(uint32_t, P_POOL); R.blob_ch = PL(unsigned short, P_BLOB_CH); R.maxch = region_maxch(h, w); R.maxdf = region_maxdf(h, w); R.gmid = PL(double, P_GMID); R.hpar = PL(int, P_HPAR); R.htime = PL(uint8_t, P_HTIME); R.hist = PL(unsigned int, P_HIST); R.lut = PL(uint8_t, P_LUT);
     R.blobs = PL(BlobRec, P_BLOBS); R.blob_d = PL(int, P_BLOB_D); R.order = PL(int, P_ORDER); R.dists = PL(double, P_DISTS);
     R.groups = PL(Group, P_GROUPS); R.best = PL(unsigned long long, P_BEST); R.lohi = PL(int, P_LOHI); R.hull = PL(int, P_HULL);
     MaskBuffers M;

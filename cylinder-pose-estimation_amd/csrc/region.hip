@@ -10,7 +10,7 @@
 // grouping runs as one wavefront per frame.  Suzuki-Abe starts every hole border at the pixel west of
 // the hole's raster-first pixel and every outer border at the component's raster-first pixel, so the
 // parallel formulation visits exactly the borders the sequential raster scan does.
-#include "sweep.h"
+#include "cpe_dev.h"
 #include <stdlib.h>
 
 namespace cpe {
@@ -178,6 +178,24 @@ struct DistVisitor {
     }
     __device__ __forceinline__ bool stop() const { return false; }
 };
+
+// ---- threshold sweep bookkeeping: per-frame int counters (SW_STRIDE ints per frame)
+constexpr int NTHR = 17;          // thresholds 50, 60, ..., 210 (SimpleBlobDetector defaults, util_cylinder.py:1836)
+constexpr int SW_STRIDE = 192;
+constexpr int NBK = NTHR + 1;     // grey-level buckets: 0: v <= 50, b: 50 + 10 (b - 1) < v <= 50 + 10 b, 17: v > 210
+enum {
+    SW_NH = 8,                    // + k: dark components away from the rectangle border at threshold k (length of hl[k])
+    SW_NL = SW_NH + NTHR,         // + k: bright components at threshold k (length of bl[k])
+    SW_NB = SW_NL + NTHR,         // + k: blobs of threshold k
+    SW_ND = SW_NB + NTHR,         // + k: border distances stored for threshold k
+    SW_BS = SW_ND + NTHR,         // + b: pixels of bucket b inside the rectangle
+    SW_BO = SW_BS + NBK,          // + b: first entry of bucket b in the bucket plane
+    SW_BC = SW_BO + NBK,          // + b: fill cursor
+    SW_NT = SW_BC + NBK,          // + k: holes of threshold k whose border is followed (length of tl[k])
+    SW_NC = SW_NT + NTHR,         // + k: border-point chunks in use
+    SW_NA = SW_NC + NTHR          // + k: blobs of threshold k that came from hole borders (they are listed first)
+};
+static_assert(SW_NA + NTHR <= SW_STRIDE, "sweep counters");
 
 // one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
 // lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
@@ -803,6 +821,333 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     if (t == 0) S.n_groups = ng;
 }
 
+// Enclosed-hole pixel totals of the bright components of every threshold, after both sweeps:
+//   encl[component (at that threshold) of the pixel west of the hole's first pixel] += |hole|
+// The bright forest of step t is read back from its merge history: an entry that stopped being a root at step j
+// carries (hpar = the root that absorbed it, htime = j); following the links with htime <= t from any pixel of the
+// step-t bright set ends at its root of step t.  One workgroup per frame walks the 17 thresholds; the totals live in
+// the accumulator plane only between the two barriers of a threshold (atomics both ways: no stale L1 lines).
+#define ENC_NT 1024
+__global__ __launch_bounds__(ENC_NT) void k_enclosed_all(const int2 *__restrict__ hl, int2 *__restrict__ bl, const int *__restrict__ sw,
+                                                         const int *__restrict__ hpar, const uint8_t *__restrict__ htime,
+                                                         int h, int w, int *__restrict__ encl)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.x;
+    const int *S = sw + f * SW_STRIDE;
+    const int *hp = hpar + f * N;
+    const uint8_t *ht = htime + f * N;
+    int *ef = encl + f * N;
+    const size_t cap = (size_t)sweep_cap(h, w);
+    for (int slot = 0; slot < NTHR; slot++) {
+        const int t = NTHR - 1 - slot;                     // bright step of this threshold
+        const int nh = min(S[SW_NH + slot], cap), nl = min(S[SW_NL + slot], cap);
+        for (int k = threadIdx.x; k < nh; k += ENC_NT) {
+            const int2 e = hl[(f * NTHR + slot) * cap + k];
+            int c = e.x - 1;                               // bright pixel west of the hole
+            while ((int)ht[c] <= t) c = hp[c];
+            atomicAdd(&ef[c], min(e.y, 5000));
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < nl; k += ENC_NT) {
+            int2 &g = bl[(f * NTHR + slot) * cap + k];
+            g.y = atomicExch(&ef[g.x], 0);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the 17 binarisations as two growing union-finds ------------------------------------------------------
+// dark set {v <= t} grows with t, bright set {v > t} grows as t falls: every pixel joins each forest once, so a
+// threshold costs one 1-B/px read of the rectangle plus unions / counts for the pixels that are new at it.
+// Roots are always the raster-first pixel of their component (larger root is linked under the smaller).
+//   new at this step: lo < v <= hi;  member: DARK ? v <= hi : v > lo
+struct SwRect { int x0, y0, x1, y1; };
+__device__ __forceinline__ SwRect sw_rect(const FrameState *st, size_t f)
+{
+    return SwRect{st[f].crect[0], st[f].crect[1], st[f].crect[2], st[f].crect[3]};
+}
+
+// ---- pixels of the rectangle sorted by the step at which they join: bucket b is new for the dark set at threshold
+// slot b and for the bright set at slot b - 1, so every later kernel of the sweep runs over a dense list
+__device__ __forceinline__ int sw_level(int v) { return v <= 50 ? 0 : min(NTHR, (v - 41) / 10); }
+constexpr int BK_CHUNK = 8192;    // pixels per workgroup of the two bucket passes
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img, int h, int w, const FrameState *__restrict__ st,
+                                                 int *__restrict__ sw, int *__restrict__ bk)
+{
+    __shared__ int s_cnt[NBK], s_base[NBK];
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int t = threadIdx.x;
+    if (t < NBK) s_cnt[t] = 0;
+    __syncthreads();
+    const SwRect r = sw_rect(st, f);
+    const uint8_t *im = img + f * N;
+    int lev[BK_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < BK_CHUNK / 256; k++) {
+        const size_t i = (size_t)blockIdx.x * BK_CHUNK + k * 256 + t;
+        int l = 0;
+        if (i < N) {
+            const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+            if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) l = sw_level(im[i]);
+        }
+        lev[k] = l;
+        if (l && !SCATTER) atomicAdd(&s_cnt[l], 1);
+        if (l && SCATTER) lev[k] = l | (atomicAdd(&s_cnt[l], 1) << 8);   // rank inside this workgroup's share
+    }
+    __syncthreads();
+    int *S = sw + f * SW_STRIDE;
+    if (!SCATTER) {
+        if (t > 0 && t < NBK && s_cnt[t]) atomicAdd(&S[SW_BS + t], s_cnt[t]);
+        return;
+    }
+    if (t > 0 && t < NBK) s_base[t] = s_cnt[t] ? atomicAdd(&S[SW_BC + t], s_cnt[t]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BK_CHUNK / 256; k++) {
+        const int l = lev[k] & 255;
+        if (l) bk[f * N + s_base[l] + (lev[k] >> 8)] = (int)((size_t)blockIdx.x * BK_CHUNK + k * 256 + t);
+    }
+}
+
+__global__ void k_bk_scan(int *sw, int n)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    int *S = sw + (size_t)f * SW_STRIDE;
+    int off = 0;
+    for (int b = 1; b < NBK; b++) { S[SW_BO + b] = off; S[SW_BC + b] = off; off += S[SW_BS + b]; }
+}
+
+constexpr int SW_GRID = 96;       // workgroups per frame of the kernels that walk one bucket (fewer in large batches: 24 at 256 images)
+
+// list entry of this lane = pixel p (negative: none): is the previous lane's entry its left neighbour in the same row?
+// (wavefront collective; k_sw_new's init pass and k_sw_unite walk the bucket lists with the same lane <-> entry mapping)
+__device__ __forceinline__ bool sw_prelinked(int p, int w, int lane)
+{
+    const int prev = __shfl_up(p, 1, 64);
+    return p >= 0 && lane > 0 && prev == p - 1 && (p % w) != 0;
+}
+
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
+                                                  const FrameState *__restrict__ st, const int *__restrict__ sw,
+                                                  const int *__restrict__ bk, int *__restrict__ P)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int *S = sw + f * SW_STRIDE;
+    const int nb = S[SW_BS + bucket];
+    const int *list = bk + f * N + S[SW_BO + bucket];
+    const SwRect r = sw_rect(st, f);
+    const uint8_t *im = img + f * N;
+    int *Pf = P + f * N;
+    // A pair of adjacent members is united by the newer pixel (the later one in raster order when both are new).
+    // Horizontal pairs always; a vertical pair only if the pair one column to the left is not also a member pair
+    // (that pair is connected by induction and joins through the two horizontal links); a diagonal pair only if
+    // neither of the two pixels completing the 2x2 square is a member.
+    auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
+    auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
+    const int lane = threadIdx.x & 63;
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
+        const int e = e0 + threadIdx.x;
+        const int i = e < nb ? list[e] : -2;
+        const bool prel = sw_prelinked(i, w, lane);   // already points at its run's first pixel (k_sw_new, init pass)
+        if (i < 0) continue;
+        const int y = i / w, x = i - y * w;
+        const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
+        auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
+        const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
+        const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
+        const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
+        if (mL && !prel) uf_unite(Pf, i, i - 1);
+        if (old(vR)) uf_unite(Pf, i, i + 1);
+        if (mU && !(mL && mem(vUL))) uf_unite(Pf, i, i - w);
+        if (old(vD) && !(mL && mem(vDL))) uf_unite(Pf, i, i + w);
+        if (!DARK) {
+            const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
+            const bool mR = mem(vR);
+            if (!mU) {
+                if (mem(vUR) && !mR) uf_unite(Pf, i, i - w + 1);
+                if (mem(vUL) && !mL) uf_unite(Pf, i, i - w - 1);
+            }
+            if (!mD) {
+                if (old(vDR) && !mR) uf_unite(Pf, i, i + w + 1);
+                if (old(vDL) && !mL) uf_unite(Pf, i, i + w - 1);
+            }
+        }
+    }
+}
+
+// rectangle border pixels of the dark set: touch[root] = epoch (such a component is not a hole, now or later)
+__global__ __launch_bounds__(256) void k_sw_touch(const uint8_t *__restrict__ img, int n, int h, int w, int hi,
+                                                  const FrameState *__restrict__ st, const int *__restrict__ P,
+                                                  uint8_t *__restrict__ touch, int epoch)
+{
+    const int per = 2 * w + 2 * h;
+    int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n * per) return;
+    int f = gi / per, k = gi - f * per;
+    const SwRect r = sw_rect(st, f);
+    if (r.x1 < r.x0) return;
+    const int rw = r.x1 - r.x0 + 1, rh = r.y1 - r.y0 + 1;
+    int x, y;
+    if (k < w) { if (k >= rw) return; x = r.x0 + k; y = r.y0; }
+    else if (k < 2 * w) { if (k - w >= rw) return; x = r.x0 + k - w; y = r.y1; }
+    else if (k < 2 * w + h) { if (k - 2 * w >= rh) return; x = r.x0; y = r.y0 + k - 2 * w; }
+    else { if (k - 2 * w - h >= rh) return; x = r.x1; y = r.y0 + k - 2 * w - h; }
+    const size_t N = (size_t)h * w;
+    const int p = y * w + x;
+    if ((int)img[f * N + p] <= hi) touch[f * N + uf_find(P + f * N, p)] = (uint8_t)epoch;
+}
+
+__device__ __forceinline__ void sw_append(bool want, int value, int *counter, int2 *list, FrameState *S, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long b = __ballot(want);
+    if (!b) return;
+    const int leader = __ffsll((long long)b) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(b));
+    base = __shfl(base, leader, 64);
+    if (want) {
+        int k = base + __popcll(b & ((1ull << lane) - 1ull));
+        if (k < cap) list[k].x = value;
+        else set_overflow(*S, OVF_SWEEP);
+    }
+}
+
+// pixels that joined at this step.  DARK: flatten, add them to their component's pixel count, list the ones that are
+// roots of components away from the rectangle border.  BRIGHT: flatten, list the ones that are roots, zero their
+// enclosed total.
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int init_bucket, FrameState *__restrict__ st,
+                                                const int *__restrict__ bk, int *__restrict__ P, int *__restrict__ acc,
+                                                const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
+                                                int *__restrict__ sw, int cnt_base, int slot,
+                                                int *__restrict__ hpar, uint8_t *__restrict__ htime)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int *S = sw + f * SW_STRIDE;
+    const int nb = S[SW_BS + bucket];
+    const int *list = bk + f * N + S[SW_BO + bucket];
+    int *Pf = P + f * N;
+    if (init_bucket >= 1 && init_bucket < NBK) {
+        // The pixels that join at the next step get their first entry now (nothing reads it before that).  Bucket lists
+        // are in raster order, so neighbouring lanes mostly hold neighbouring pixels of a row: such a run is linked to its
+        // first pixel right here, with plain stores, and k_sw_unite (same lane <-> entry mapping, see sw_prelinked) skips
+        // the union with the left neighbour for them -- about half of all unions, each a memory-side atomic.
+        const int ni = S[SW_BS + init_bucket];
+        const int *li = bk + f * N + S[SW_BO + init_bucket];
+        for (int e0 = blockIdx.x * 256; e0 < ni; e0 += gridDim.x * 256) {
+            const int e = e0 + threadIdx.x;
+            const int p = e < ni ? li[e] : -2;
+            const bool linked = sw_prelinked(p, w, lane);
+            const unsigned long long starts = __ballot(p >= 0 && !linked);
+            if (p >= 0) {
+                const unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+                Pf[p] = p - (lane - (63 - __clzll(m)));
+            }
+        }
+    }
+    if (bucket < 1) return;
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
+        const int e = e0 + threadIdx.x;
+        const bool isnew = e < nb;
+        int i = -1, root = -1;
+        if (isnew) {
+            i = list[e];
+            root = uf_find_c(Pf, i);
+            if (root != i) {
+                Pf[i] = root;
+                if (!DARK) { hpar[f * N + i] = root; htime[f * N + i] = (uint8_t)epoch; }   // joined `root` at this step
+            }
+        }
+        bool is_root = isnew && root == i;
+        if (DARK) {
+            is_root = is_root && touch[f * N + i] != (uint8_t)epoch;
+            int key = root;
+            unsigned long long active = __ballot(key >= 0);
+            while (active) {
+                int leader = __ffsll((long long)active) - 1;
+                int lk = __shfl(key, leader, 64);
+                unsigned long long same = __ballot(key == lk) & active;
+                if (lane == leader) atomicAdd(&acc[f * N + lk], __popcll(same));
+                active &= ~same;
+            }
+        } else if (is_root) acc[f * N + i] = 0;
+        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * (size_t)sweep_cap(h, w), &st[f], sweep_cap(h, w));
+    }
+}
+
+// components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
+// Merged into another (DARK): hand its pixel count to the component that absorbed it.
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_elem_stride, int src_cap,
+                                                const int *__restrict__ src_cnt, int src_cnt_stride,
+                                                int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
+                                                int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
+                                                int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                                int *__restrict__ hpar, uint8_t *__restrict__ htime)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const int ns = min(src_cnt[f * src_cnt_stride], src_cap);
+    for (int k0 = blockIdx.x * 256; k0 < ns; k0 += gridDim.x * 256) {   // wave-uniform: sw_append is a wavefront collective
+    const int k = k0 + threadIdx.x;
+    bool keep = false;
+    int r = 0;
+    if (k < ns) {
+        r = src[f * src_frame_stride + (size_t)k * src_elem_stride];
+        int *Pf = P + f * N;
+        if (DARK) {
+            if (touch[f * N + r] != (uint8_t)epoch) {
+                if (uf_load(Pf, r) == r) keep = true;
+                else atomicAdd(&acc[f * N + uf_find_c(Pf, r)], acc[f * N + r]);
+            }
+        } else {
+            keep = uf_load(Pf, r) == r;
+            if (keep) acc[f * N + r] = 0;
+            else { hpar[f * N + r] = uf_find_c(Pf, r); htime[f * N + r] = (uint8_t)epoch; }   // absorbed at this step
+        }
+    }
+    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * (size_t)sweep_cap(h, w), &st[f], sweep_cap(h, w));
+    }
+}
+
+// freeze the per-component totals of threshold slot `slot` next to the roots: the accumulator plane moves on
+// trace (optional): the entries whose border has to be followed go to a dense list of their own, so the lanes of a
+// wavefront of k_blob_trace walk borders of similar length.  A hole of n <= 3 pixels spans at most 1x3 or 2x2 pixels,
+// its border polygon runs through pixels 8-adjacent to it, so its area is at most 2x4 or 3x3 < 10 = minArea;
+// a hole of n >= 5000 pixels has a border polygon of area >= n >= maxArea.
+__global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                                 int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
+{
+    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const size_t cap = (size_t)sweep_cap(h, w);
+    const int cnt = min(sw[f * SW_STRIDE + cnt_base + slot], (int)cap);
+    const int lane = threadIdx.x & 63;
+    for (int k0 = blockIdx.x * 256; k0 < cnt; k0 += gridDim.x * 256) {
+        const int k = k0 + threadIdx.x;
+        const bool valid = k < cnt;
+        int2 e = make_int2(0, 0);
+        if (valid) {
+            int2 &g = lists[(f * NTHR + slot) * cap + k];
+            g.y = acc[f * N + g.x];
+            e = g;
+        }
+        if (!trace) continue;
+        const bool want = valid && e.y > 3 && e.y < 5000;
+        unsigned long long b = __ballot(want);
+        if (!b) continue;
+        const int leader = __ffsll((long long)b) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
+        base = __shfl(base, leader, 64);
+        if (want) trace[(f * NTHR + slot) * cap + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
+    }
+}
+
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
 __global__ __launch_bounds__(256) void k_discs(FrameState *__restrict__ st, const Group *__restrict__ groups, int h, int w,
                                                uint8_t *__restrict__ ext)
@@ -1096,37 +1441,85 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         (void)hipStreamWaitEvent(side->s, side->clahe_done, 0);
         if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, side->s)) != CPE_OK) return rc;
     }
-    // working rectangle of the sweep = bounding box of the pixels brighter than the lowest threshold: every brighter set and
-    // every hole of every binarisation lies inside it
+    // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
+    // every brighter set and every hole of every binarisation lies inside it
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
+    (void)hipMemsetAsync(B.touch, 0, total, s);
     const int swcap = sweep_cap(h, w);
-    const dim3 gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR);
-    SweepBuffers W;
-    W.cl = B.cl; W.G = B.lab; W.acc = B.cnt; W.tch = B.touch; W.sw = B.sw;
-    W.pool = reinterpret_cast<int2 *>(B.bk); W.pool_cap = (int)(N / 2);
-    W.bh = B.swbh; W.bcap = sw_tiles_x(w) * sw_tiles_y(h);
-    W.hb_off = B.hboff; W.hb_ent = reinterpret_cast<int2 *>(B.hpar); W.hb_cap = (int)(N / 2);
-    W.hl = B.hl; W.bl = B.bl; W.tl = B.tl;
-    { const char *e = getenv("CPE_SW_DBG"); W.dbg = e ? atoi(e) : 0; }
-    // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count), B.tl[k] = the
-    // ones whose border is followed
-    if ((rc = sweep_dark(W, n, h, w, st, s)) != CPE_OK) return rc;
-    // the hole borders and their radii run on the helper stream (if any) beside the bright sweep
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
+    {
+        const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
+        CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
+        CPE_KLAUNCH(k_bk_scan, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
+        CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
+        CPE_CHECK_LAUNCH("grey-level buckets");
+    }
+    const int per = 2 * w + 2 * h;
+    const size_t lstride = (size_t)NTHR * swcap * 2;   // ints per frame of a list array
+    // the dark sweep and the hole borders run on the helper stream (if any) beside the bright sweep: the two forests
+    // only meet in k_enclosed_all
     hipStream_t ds = side ? side->s : s;
-    if (side) {
-        (void)hipEventRecord(side->dark_done, s);
-        (void)hipStreamWaitEvent(ds, side->dark_done, 0);
-    } else if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_blob_trace<1>, gtrace_h, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
-                B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
-    CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
-    CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 16, 128), n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
-                (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
-    if (side) (void)hipEventRecord(side->medians, ds);
+    if (side) { (void)hipEventRecord(side->dark_done, s); (void)hipStreamWaitEvent(ds, side->dark_done, 0); }
+    // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count)
+    for (int k = 0; k < NTHR; k++) {
+        const int thr = 50 + 10 * k, epoch = k + 1;
+        if (k == 0) {
+            // the bulk of the dark set: run-based labelling, flattened; pixels outside it start as singletons
+            if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 2)) != CPE_OK) return rc;
+            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
+                        (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
+            // first entries of the pixels that join at the next step (bucket 1)
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, 0, 1, st, (const int *)B.bk, B.lab, B.cnt,
+                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+            CPE_KLAUNCH(k_sw_old<true>, dim3(frame_waves(n, 8, MAXROOTS / 256), n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
+                        (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
+                        B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+        } else {
+            CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, ds, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
+                        (const int *)B.sw, (const int *)B.bk, B.lab);
+            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
+                        (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
+            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, k + 1 < NTHR ? k + 1 : 0, st, (const int *)B.bk, B.lab, B.cnt,
+                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)B.hl + (size_t)(k - 1) * swcap * 2, lstride, 2, swcap,
+                        (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
+                        B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+        }
+        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, ds, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
+        CPE_CHECK_LAUNCH("blob sweep (dark)");
+    }
+    {
+        // hole borders of all thresholds and their radii
+        if (!side && (rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
+        CPE_KLAUNCH(k_blob_trace<1>, gtrace_h, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
+                    B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
+        CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
+        CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 16, 128), n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
+                    (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
+        if (side) (void)hipEventRecord(side->medians, ds);
+    }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
-    if ((rc = sweep_bright(W, n, h, w, st, s)) != CPE_OK) return rc;
+    // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
+    (void)hipMemsetAsync(B.htime, 0xFF, total, s);
+    CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
+                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0, B.hpar, B.htime);
+    for (int j = 0; j < NTHR; j++) {
+        const int k = NTHR - 1 - j, thr = 50 + 10 * k;
+        const int hi = j == 0 ? 255 : thr + 10;
+        CPE_KLAUNCH(k_sw_unite<false>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, k + 1, (const FrameState *)st,
+                    (const int *)B.sw, (const int *)B.bk, B.lab2);
+        CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
+                    (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
+        if (j > 0)
+            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * swcap * 2, lstride, 2, swcap,
+                        (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, j,
+                        B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
+        CPE_CHECK_LAUNCH("blob sweep (bright)");
+    }
     if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
+    CPE_KLAUNCH(k_enclosed_all, dim3(n), dim3(ENC_NT), 0, s, (const int2 *)B.hl, B.bl, (const int *)B.sw, (const int *)B.hpar,
+                (const uint8_t *)B.htime, h, w, B.cnt2);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
     CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 8, 32), n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
