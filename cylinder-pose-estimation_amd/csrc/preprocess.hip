@@ -16,6 +16,7 @@
 // bit-identical to the CPU oracle, which in turn is bit-identical to the real skimage for b.
 // HBM traffic per frame: h*w read (+ tile halo re-reads served by L2) + h*w written.
 #include "cpe_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -66,30 +67,50 @@ struct GView {
     }
 };
 
+// A workgroup is persistent: it walks tiles tile0, tile0 + 1, ... of its share.  The shares are laid out so that the
+// workgroups of one XCD (blockIdx % 8 under round-robin placement: speed only) work on neighbouring tiles at the same time
+// and find each other's halos in their L2.  The gray window of the NEXT tile is requested from HBM while the current tile
+// is in its f64 phases (the window buffer is free after phase B) and stored into LDS late in the iteration, so its latency
+// is hidden behind the arithmetic instead of being waited for with one workgroup per CU and nothing else to run.
+constexpr int A_DW = AH * (AW / 4);                 // dwords of the gray window
+constexpr int A_PER = (A_DW + NT - 1) / NT;         // per thread
 __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ gray, int h, int w,
-                                                   int tiles_x, int tiles_y,
+                                                   int tiles_x, int tiles_y, long long total_tiles,
                                                    uint8_t *__restrict__ mask)
 {
     __shared__ Smem s;
     const int tid = threadIdx.x;
-    // blockIdx.x -> (frame, tile); tiles of one frame are consecutive so they share L2 halos
     const int tiles = tiles_x * tiles_y;
-    const int frame = blockIdx.x / tiles;
-    const int t = blockIdx.x - frame * tiles;
+    // this workgroup's tiles: XCD x = blockIdx % 8 owns the contiguous range [x * per_xcd, (x + 1) * per_xcd); its workgroups
+    // (slot j of nslot) take tiles j, j + nslot, ... of that range
+    const int nslot = gridDim.x / 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const long long per_xcd = (total_tiles + 7) / 8;
+    const long long range_lo = xcd * per_xcd, range_hi = range_lo + per_xcd < total_tiles ? range_lo + per_xcd : total_tiles;
+    auto fast_tile = [&](long long tix, const uint8_t *&img_out, int &gx0_out, int &gy0_out) -> bool {
+        const int frame = (int)(tix / tiles), t = (int)(tix - (long long)frame * tiles);
+        gx0_out = (t % tiles_x) * TX; gy0_out = (t / tiles_x) * TY;
+        img_out = gray + (size_t)frame * h * w;
+        return ((w & 3) == 0) && ((((size_t)img_out) & 3) == 0) && gx0_out - 24 >= 0 && gx0_out - 24 + AW <= w &&
+               gy0_out - RA >= 0 && gy0_out - RA + AH <= h;
+    };
+    bool have_a = false;                              // s.a already holds the window of the tile about to be processed
+    for (long long tix = range_lo + slot; tix < range_hi; tix += nslot) {
+    const int frame = (int)(tix / tiles);
+    const int t = (int)(tix - (long long)frame * tiles);
     const int gx0 = (t % tiles_x) * TX, gy0 = (t / tiles_x) * TY;
     const uint8_t *img = gray + (size_t)frame * h * w;
     uint8_t *out = mask + (size_t)frame * h * w;
 
     // A: gray with reflect-101 addressing; LDS column j is x = gx0 - 24 + j.  Tiles whose window lies inside the
     // frame (and whose rows are 4-byte aligned in memory) move dwords, the others single bytes.
-    {
+    if (!have_a) {
         const bool fast = ((w & 3) == 0) && ((((size_t)img) & 3) == 0) && gx0 - 24 >= 0 && gx0 - 24 + AW <= w &&
                           gy0 - RA >= 0 && gy0 - RA + AH <= h;
         if (fast) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (size_t)(gy0 - RA) * w + (gx0 - 24));
             uint32_t *dst = reinterpret_cast<uint32_t *>(s.a);
             const int wq = w >> 2;
-            for (int i = tid; i < AH * (AW / 4); i += NT) {
+            for (int i = tid; i < A_DW; i += NT) {
                 int ry = i / (AW / 4), q = i - ry * (AW / 4);
                 dst[i] = src[(size_t)ry * wq + q];
             }
@@ -141,6 +162,26 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         }
     }
     __syncthreads();
+    // request the next tile's window (interior tiles only: the others are loaded at the top of their iteration)
+    uint32_t pre[A_PER];
+    bool pre_ok = false;
+    {
+        const long long nix = tix + nslot;
+        if (nix < range_hi) {
+            const uint8_t *nimg; int ngx0, ngy0;
+            if (fast_tile(nix, nimg, ngx0, ngy0)) {
+                pre_ok = true;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(nimg + (size_t)(ngy0 - RA) * w + (ngx0 - 24));
+                const int wq = w >> 2;
+#pragma unroll
+                for (int k = 0; k < A_PER; k++) {
+                    const int i = tid + k * NT;
+                    const int ry = i / (AW / 4), q = i - ry * (AW / 4);
+                    pre[k] = i < A_DW ? src[(size_t)ry * wq + q] : 0u;
+                }
+            }
+        }
+    }
 
     const double inv255 = 1.0 / 255;
     // C: Gaussian along y.  V = 0 outside the image (the x pass zero-pads).
@@ -251,6 +292,12 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         }
     }
     __syncthreads();
+    if (pre_ok) {   // the window requested after phase B has arrived long ago
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s.a);
+#pragma unroll
+        for (int k = 0; k < A_PER; k++) { const int i = tid + k * NT; if (i < A_DW) dst[i] = pre[k]; }
+    }
+    have_a = pre_ok;
 
     // F/G: 15x15 box of b and b*b (row sums left->right, then column sums top->bottom).  Register windows again:
     // a thread makes KF neighbouring row sums from KF + 14 inputs, and the 4 column sums of its 4 output pixels
@@ -270,11 +317,16 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
                 double v = bb[ry * EWP + tx0 + k];
                 cv[k] = squared ? v * v : v;
             }
+            static_assert(KF == 8 && TX % 8 == 0, "row-sum blocks are 8 columns, aligned to the image origin");
+            // cv2's RowSum: a direct sum for the block's first output, then s += in - out (block = the KF outputs of
+            // this thread: columns x0 .. x0 + 7 with x0 a multiple of 8 in image coordinates)
+            double acc = 0.0;
 #pragma unroll
-            for (int o = 0; o < KF; o++) {
-                double acc = 0.0;
+            for (int j = 0; j < 15; j++) acc = acc + cv[j];
+            rs[ry * RSP + tx0] = acc;
 #pragma unroll
-                for (int j = 0; j < 15; j++) acc = acc + cv[o + j];
+            for (int o = 1; o < KF; o++) {
+                acc = acc + (cv[o + 14] - cv[o - 1]);
                 rs[ry * RSP + tx0 + o] = acc;
             }
         }
@@ -283,11 +335,14 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         double cv[KG + 14];
 #pragma unroll
         for (int k = 0; k < KG + 14; k++) cv[k] = rs[(oty0 + k) * RSP + otx];
+        // cv2's ColumnSum: s0 = SUM + Sp, SUM = s0 - Sm (block = this thread's KG rows, y0 a multiple of 4)
+        double acc = 0.0;
 #pragma unroll
-        for (int o = 0; o < KG; o++) {
-            double acc = 0.0;
+        for (int j = 0; j < 15; j++) acc = acc + cv[j];
+        res[0] = acc * (1.0 / 225.0);
 #pragma unroll
-            for (int j = 0; j < 15; j++) acc = acc + cv[o + j];
+        for (int o = 1; o < KG; o++) {
+            acc = (acc - cv[o - 1]) + cv[o + 14];
             res[o] = acc * (1.0 / 225.0);
         }
     };
@@ -311,6 +366,8 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
         double bv = bb[(ty + RE) * EWP + tx + RE];
         if (y < h && x < w) out[(size_t)y * w + x] = (bv > T) ? 0 : 255;
     }
+    __syncthreads();   // the next tile's phases overwrite b5 / buf1 / buf2
+    }
 }
 
 }  // namespace
@@ -322,11 +379,20 @@ extern "C" int32_t cpe_preprocess_batch(const uint8_t *gray, int32_t n, int32_t 
     CPE_CHECK_ARG(n >= 0 && h >= 8 && w >= 8, "cpe_preprocess_batch: need n>=0, h,w>=8 (got %d,%d,%d)", n, h, w);
     if (n == 0) return CPE_OK;
     int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
-    long long blocks = (long long)n * tiles_x * tiles_y;
-    CPE_CHECK_ARG(blocks < (1LL << 31), "cpe_preprocess_batch: grid too large");
+    const long long blocks = (long long)n * tiles_x * tiles_y;
+    // persistent workgroups, one per CU (the tile buffers take the CU's LDS); a multiple of 8 so that every XCD gets the same
+    static int cu_count[64] = {0};                    // per device, filled on first use (identical values if threads race)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cu_count[dev] == 0) {
+        int v = 0;
+        cu_count[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) ? v / 8 * 8 : 256;
+    }
+    const int cus = cu_count[dev];
+    const unsigned grid = (unsigned)std::min<long long>(cus, (blocks + 7) / 8 * 8);
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_preprocess, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gray, h, w,
-                       tiles_x, tiles_y, mask);
+    CPE_KLAUNCH(k_preprocess, dim3(grid), dim3(NT), 0, (hipStream_t)stream, gray, h, w,
+                       tiles_x, tiles_y, blocks, mask);
     CPE_CHECK_LAUNCH("k_preprocess");
     return CPE_OK;
 }

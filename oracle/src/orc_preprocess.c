@@ -140,37 +140,58 @@ ORC_API void orc_hessian_eigs(const double *G, int h, int w, double *emin, doubl
  * mask = 255 where b <= T (ridges), 0 where b > T. */
 ORC_API void orc_sauvola_mask(const double *b, int h, int w, uint8_t *mask)
 {
-    const int r = 7;
+    /* Box sums as cv2.boxFilter forms them (RowSum / ColumnSum of box_filter: a direct sum for the first output, then
+     * one value in and one out per step), with the running sums restarted every 8 columns / 4 rows (positions aligned to
+     * the image origin) so that blocks are independent: OpenCV's own sums run along the whole row / column, which no
+     * parallel evaluation reproduces bit for bit.  [ext], parity unpinned. */
+    const int r = 7, BX = 8, BY = 4;
     const double scale = 1.0 / 225.0; /* 1./(ksize.width*ksize.height) */
     double *rs = (double *)malloc((size_t)h * w * sizeof(double));
     double *rs2 = (double *)malloc((size_t)h * w * sizeof(double));
-    for (int y = 0; y < h; y++)
+    for (int y = 0; y < h; y++) {
+        const double *row = b + (size_t)y * w;
+        double s = 0.0, s2 = 0.0;
         for (int x = 0; x < w; x++) {
-            double s = 0.0, s2 = 0.0;
-            for (int j = -r; j <= r; j++) {
-                double v = b[(size_t)y * w + orc_clampi(x + j, 0, w - 1)];
-                s = s + v;
-                s2 = s2 + v * v;
+            if (x % BX == 0) {
+                s = 0.0; s2 = 0.0;
+                for (int j = -r; j <= r; j++) {
+                    double v = row[orc_clampi(x + j, 0, w - 1)];
+                    s = s + v;
+                    s2 = s2 + v * v;
+                }
+            } else {           /* RowSum: s += S[i + ksz] - S[i] */
+                double vin = row[orc_clampi(x + r, 0, w - 1)], vout = row[orc_clampi(x - r - 1, 0, w - 1)];
+                s = s + (vin - vout);
+                s2 = s2 + (vin * vin - vout * vout);
             }
             rs[(size_t)y * w + x] = s;
             rs2[(size_t)y * w + x] = s2;
         }
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            double s = 0.0, s2 = 0.0;
-            for (int j = -r; j <= r; j++) {
-                size_t o = (size_t)orc_clampi(y + j, 0, h - 1) * w + x;
-                s = s + rs[o];
-                s2 = s2 + rs2[o];
+    }
+    for (int x = 0; x < w; x++) {
+        double c = 0.0, c2 = 0.0;
+        for (int y = 0; y < h; y++) {
+            if (y % BY == 0) {
+                c = 0.0; c2 = 0.0;
+                for (int j = -r; j <= r; j++) {
+                    size_t o = (size_t)orc_clampi(y + j, 0, h - 1) * w + x;
+                    c = c + rs[o];
+                    c2 = c2 + rs2[o];
+                }
+            } else {           /* ColumnSum: SUM = s0 - Sm (after the previous output), s0 = SUM + Sp */
+                size_t oin = (size_t)orc_clampi(y + r, 0, h - 1) * w + x, oout = (size_t)orc_clampi(y - r - 1, 0, h - 1) * w + x;
+                c = (c - rs[oout]) + rs[oin];
+                c2 = (c2 - rs2[oout]) + rs2[oin];
             }
-            double mean = s * scale;
-            double mean_sq = s2 * scale;
+            double mean = c * scale;
+            double mean_sq = c2 * scale;
             double var = mean_sq - mean * mean;
             if (var < 0) var = 0;
             double sd = sqrt(var);
             double T = mean * (1 + 0.5 * ((sd / 128) - 1));
             mask[(size_t)y * w + x] = (b[(size_t)y * w + x] > T) ? 0 : 255;
         }
+    }
     free(rs);
     free(rs2);
 }

@@ -7,10 +7,11 @@ b = synth.render_batch(n // 2, 1200, 1920, seed=1, device='cuda', with_gt=False)
 frames = torch.cat([b['left'], b['right']]); out = torch.empty_like(frames)
 L = cpe_amd.lib.load()
 def run(): cpe_amd.lib.check(L.cpe_preprocess_batch(frames.data_ptr(), n, 1200, 1920, out.data_ptr(), torch.cuda.current_stream().cuda_stream), 'pp')
-run(); torch.cuda.synchronize()
-e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): run()
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
-print(f'k_preprocess: {ms:.2f} ms per launch of {n} images = {1e3*ms/n:.1f} us/img; algorithmic {2*n*1200*1920/ms/1e6:.1f} GB/s')
+for dbg in [0]:
+    run(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f'dbg {dbg} k_preprocess: {ms:.2f} ms per launch of {n} images = {1e3*ms/n:.1f} us/img; algorithmic {2*n*1200*1920/ms/1e6:.1f} GB/s')
