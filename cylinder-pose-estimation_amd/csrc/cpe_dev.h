@@ -21,7 +21,7 @@ constexpr int MAXG_LDS = 2048;   // ... whose middle centres sit in k_blob_merge
 constexpr int GCAP = 64;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = 128;        // grid lines per direction (label groups of the joints: noise joints make extra ones)
-constexpr int MAXLP = 128;       // joints per grid line (a line meets at most MAXL lines of the other direction)
+constexpr int MAXLP = 256;       // joints per label group (rows whose expanded masks touch share one: 4 x 39 seen on a 4K frame)
 constexpr int MAXSEG = 2048;     // line fragments per mask in the expansion stage
 
 struct CompRec {        // one traced border

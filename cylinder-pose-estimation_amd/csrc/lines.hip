@@ -20,6 +20,8 @@ struct LinesWS {
     int ent_id[MAXL * MAXL][2];
     int gn[2][MAXL], in[2][MAXL], glabel[2][MAXL];
     unsigned char ival[MAXL][MAXL];
+    double fit_scr[2][MAXL][7 * MAXLP];   // per-line scratch of the fits: sorted abscissae / ordinates, QR columns
+    int fit_ord[2][MAXL][MAXLP];
     int fin_ord[2][MAXL], fin_n[2];  // lines that survive clean_and_relabel, in their final order (row1.., col1..)
 };
 
@@ -30,9 +32,12 @@ namespace {
 __device__ __forceinline__ double polyval2(const double *c, double x) { return (c[0] * x + c[1]) * x + c[2]; }
 
 // np.polyfit(x, y, 2) as restated in the oracle: column-scaled Vandermonde + Householder QR
-__device__ void polyfit2(const double *x, const double *y, int n, double *coef)
+// scr: 5 n doubles of scratch (the per-line slots of LinesWS: a line may hold MAXLP points, too many for the stack)
+__device__ void polyfit2(const double *x, const double *y, int n, double *coef, double *scr)
 {
-    double A[MAXLP][3], b[MAXLP], scale[3], v[MAXLP];
+    double (*A)[3] = reinterpret_cast<double (*)[3]>(scr);
+    double *b = scr + 3 * n, *v = scr + 4 * n;
+    double scale[3];
     for (int i = 0; i < n; i++) { A[i][0] = x[i] * x[i]; A[i][1] = x[i]; A[i][2] = 1.0; b[i] = y[i]; }
     for (int c = 0; c < 3; c++) {
         double s = 0;
@@ -71,9 +76,11 @@ __device__ void polyfit2(const double *x, const double *y, int n, double *coef)
 }
 
 // np.polyfit(x, y, 1) (planar script, util_plane.py:411-634): column-scaled n x 2 Vandermonde + Householder QR
-__device__ void polyfit1(const double *x, const double *y, int n, double *coef)
+__device__ void polyfit1(const double *x, const double *y, int n, double *coef, double *scr)
 {
-    double A[MAXLP][2], b[MAXLP], scale[2], v[MAXLP];
+    double (*A)[2] = reinterpret_cast<double (*)[2]>(scr);
+    double *b = scr + 2 * n, *v = scr + 3 * n;
+    double scale[2];
     for (int i = 0; i < n; i++) { A[i][0] = x[i]; A[i][1] = 1.0; b[i] = y[i]; }
     for (int c = 0; c < 2; c++) {
         double s = 0;
@@ -109,10 +116,9 @@ __device__ void polyfit1(const double *x, const double *y, int n, double *coef)
 }
 
 // sort n points of a line by coordinate kc (stable), fit the other coordinate: coef (c1, c0), range of the abscissa
-__device__ void fit_line_sorted(const double (*pts)[2], int n, int kc, double *coef, double &lo, double &hi)
+__device__ void fit_line_sorted(const double (*pts)[2], int n, int kc, double *coef, double &lo, double &hi, double *scr, int *ord)
 {
-    double tt[MAXLP], uu[MAXLP];
-    int ord[MAXLP];
+    double *tt = scr, *uu = scr + n;
     for (int i = 0; i < n; i++) ord[i] = i;
     for (int a = 1; a < n; a++) {
         int o = ord[a];
@@ -121,7 +127,7 @@ __device__ void fit_line_sorted(const double (*pts)[2], int n, int kc, double *c
         ord[b + 1] = o;
     }
     for (int i = 0; i < n; i++) { tt[i] = pts[ord[i]][kc]; uu[i] = pts[ord[i]][1 - kc]; }
-    polyfit1(tt, uu, n, coef);
+    polyfit1(tt, uu, n, coef, scr + 2 * n);
     lo = tt[0]; hi = tt[n - 1];
 }
 
@@ -399,14 +405,14 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                 // degree 1; rows get their final +-50 domain, columns a provisional +-10 one (merged below)
                 if (n >= 2) {
                     double c[2], lo, hi;
-                    fit_line_sorted((const double (*)[2])W.gpts[sd][g], n, sd == 0 ? 0 : 1, c, lo, hi);
+                    fit_line_sorted((const double (*)[2])W.gpts[sd][g], n, sd == 0 ? 0 : 1, c, lo, hi, W.fit_scr[sd][g], W.fit_ord[sd][g]);
                     const double mg = sd == 0 ? 50.0 : 10.0;
                     lo -= mg; hi += mg;
                     W.eq[sd][g][0] = c[0]; W.eq[sd][g][1] = c[1]; W.eq[sd][g][2] = lo; W.eq[sd][g][3] = hi; W.eq[sd][g][4] = fabs(lo - hi);
                 }
             } else if (n >= 3) {
-                double tt[MAXLP], uu[MAXLP];
-                int ord[MAXLP];
+                double *tt = W.fit_scr[sd][g], *uu = tt + n;
+                int *ord = W.fit_ord[sd][g];
                 const int kc = sd == 0 ? 0 : 1;  // rows: y = f(x) sorted by x; cols: x = f(y) sorted by y
                 for (int i = 0; i < n; i++) ord[i] = i;
                 for (int a = 1; a < n; a++) {
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                 }
                 for (int i = 0; i < n; i++) { tt[i] = W.gpts[sd][g][ord[i]][kc]; uu[i] = W.gpts[sd][g][ord[i]][1 - kc]; }
                 double c[3];
-                polyfit2(tt, uu, n, c);
+                polyfit2(tt, uu, n, c, tt + 2 * n);
                 double lo = tt[0] - 50, hi = tt[n - 1] + 50;
                 W.eq[sd][g][0] = c[0]; W.eq[sd][g][1] = c[1]; W.eq[sd][g][2] = c[2];
                 W.eq[sd][g][3] = lo; W.eq[sd][g][4] = hi; W.eq[sd][g][5] = fabs(hi - lo);
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                 W.gn[1][slot] = cnt;
                 if (cnt >= 2) {
                     double c[2], lo, hi;
-                    fit_line_sorted((const double (*)[2])W.gpts[1][slot], cnt, 1, c, lo, hi);
+                    fit_line_sorted((const double (*)[2])W.gpts[1][slot], cnt, 1, c, lo, hi, W.fit_scr[1][slot], W.fit_ord[1][slot]);
                     W.eq[1][slot][0] = c[0]; W.eq[1][slot][1] = c[1]; W.eq[1][slot][2] = lo; W.eq[1][slot][3] = hi; W.eq[1][slot][4] = fabs(lo - hi);
                     s_ord[1][m++] = slot;
                 }   // else: the members are deleted and nothing takes their place

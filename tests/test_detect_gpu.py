@@ -272,3 +272,25 @@ def test_fragment_inside_a_hole_of_another_is_dropped(cpe, orc, gpu):
     assert n_ext < n_all                                    # the nesting exists at this call site
     n_ok = _compare(cpe, orc, gpu, torch.from_numpy(np.stack([img, b['right'][0].numpy()])))
     assert n_ok == 2
+
+
+@pytest.mark.gpu
+def test_no_capacity_overflow_on_clean_4k_frames(cpe, gpu):
+    """BASELINE config 5's frame size: 64 clean synthetic 3840x2160 images, none may end in the build-defined status 6.
+    (Round 1 lost 8.6 % of them to the 1024-point tables and to 64 joints per label group; a frame whose expanded row
+    masks touch puts 4 x 39 joints into one group.)"""
+    from cpe_amd import synth
+    b = synth.render_batch(32, 2160, 3840, seed=1000, device='cuda', with_gt=False)
+    ws = None
+    worst = 0
+    for part in (b['left'], b['right']):
+        for i0 in range(0, 32, 8):
+            frames = part[i0:i0 + 8].contiguous()
+            if ws is None:
+                ws = cpe.api.DetectWorkspace(8, 2160, 3840, frames.device)
+            det = cpe.api.detect_grid_batch(frames, ws)
+            torch.cuda.synchronize()
+            st = det['status'].cpu().tolist()
+            assert st == [0] * 8, (i0, st, [s['overflow'] for s in ws.state()])
+            worst = max(worst, int(det['n'].max()))
+    assert 600 < worst <= cpe.fit.MAXP
