@@ -315,7 +315,7 @@ def run_rank(args):
         K1, K2, T21, radius = base['K1'], base['K2'], base['T21'], base['radius']
         del base
         pipe = pipeline.FramePipeline(H, W, K1, K2, T21, radius, chunk=min(args.chunk, max(F, 1)), device=dev,
-                                      fit_mode=1 if (args.fit_mode == 'lm' or args.ransac) else 0,
+                                      fit_mode=1 if (args.fit_mode == 'lm' or args.ransac) else 0, lanes=args.lanes,
                                       ransac=dict(hypotheses=args.ransac, seed=2026, frame0=lo) if args.ransac else None)
 
     def sync():
@@ -442,6 +442,7 @@ def main():
                     help='default: strong for N > 1 (BASELINE.json configs[3]: the 4096-frame batch sharded N x)')
     ap.add_argument('--chunk', type=int, default=0,
                     help='stereo frames per kernel batch (workspace size); 0 = 256 at 1920x1200, 64 at 3840x2160')
+    ap.add_argument('--lanes', type=int, default=1, help='chunks in flight, each on its own HIP stream with its own workspace')
     ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes (cycled with fresh noise)')
     ap.add_argument('--fit-mode', choices=['nm', 'lm'], default='nm',
                     help='nm = fminsearch clone (reference behaviour, default); lm = Levenberg-Marquardt fast mode')

@@ -690,33 +690,79 @@ __global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict_
         if (r.x0 >= x0 && r.x0 < x0 + 64) edge |= 1ull << (r.x0 - x0);
         if (r.x1 >= x0 && r.x1 < x0 + 64) edge |= 1ull << (r.x1 - x0);
     }
+    // Rows are loaded ahead of their use: the flood of a row only needs the previous row's result (a register), so the
+    // next chunk of rows is requested before the current one is worked on and the memory round trip -- what a
+    // row-at-a-time loop spends nearly all its time on -- overlaps the arithmetic.
+    constexpr int CHUNK = 8;
+    const int nrows = r.y1 - r.y0 + 1;
     // sweep 0 (down): pack the background once, seed from the window border
     unsigned long long prev = ~0ull;   // the row above the window is all outside
-    for (int y = r.y0; y <= r.y1; y++) {
-        unsigned long long bg = 0;
-        if (lane < WW) bg = ~pack_nonzero64(im + (size_t)y * w, x0, w) & cmask;
-        unsigned long long seed = (prev | edge) & bg;
-        if (y == r.y1) seed = bg;      // the row below the window is all outside
-        const unsigned long long o = flood_row(bg, seed, lane, WW);
-        if (lane < WW) { bgw[(size_t)y * WW + lane] = bg; out[(size_t)y * WW + lane] = o; }
-        prev = o;
+    {
+        unsigned long long nxt[CHUNK];
+        auto load0 = [&](int k0, unsigned long long *dst) {
+#pragma unroll
+            for (int k = 0; k < CHUNK; k++) {
+                const int y = r.y0 + k0 + k;
+                dst[k] = (lane < WW && k0 + k < nrows) ? (~pack_nonzero64(im + (size_t)y * w, x0, w) & cmask) : 0ull;
+            }
+        };
+        load0(0, nxt);
+        for (int k0 = 0; k0 < nrows; k0 += CHUNK) {
+            unsigned long long bgc[CHUNK];
+#pragma unroll
+            for (int k = 0; k < CHUNK; k++) bgc[k] = nxt[k];
+            if (k0 + CHUNK < nrows) load0(k0 + CHUNK, nxt);
+#pragma unroll
+            for (int k = 0; k < CHUNK; k++) {
+                if (k0 + k >= nrows) break;
+                const int y = r.y0 + k0 + k;
+                const unsigned long long bg = bgc[k];
+                unsigned long long seed = (prev | edge) & bg;
+                if (y == r.y1) seed = bg;      // the row below the window is all outside
+                // most rows of a sparse mask: every background pixel has outer background right above it
+                const unsigned long long o = __ballot(seed != bg) ? flood_row(bg, seed, lane, WW) : bg;
+                if (lane < WW) { bgw[(size_t)y * WW + lane] = bg; out[(size_t)y * WW + lane] = o; }
+                prev = o;
+            }
+        }
     }
-    // further sweeps, alternating direction, until nothing changes (this wavefront's own stores: visible to it in order)
+    // further sweeps, alternating direction, until nothing changes (this wavefront's own stores: visible to it in order;
+    // a row's entry is only rewritten by the step that works on that row, so loading it a chunk early is safe)
     for (int pass = 1; pass < 4096; pass++) {
         const bool upw = pass & 1;
         bool any = false;
         prev = ~0ull;
-        for (int k = r.y0; k <= r.y1; k++) {
-            const int y = upw ? r.y1 - (k - r.y0) : k;
-            unsigned long long bg = 0, cur = 0;
-            if (lane < WW) { bg = bgw[(size_t)y * WW + lane]; cur = out[(size_t)y * WW + lane]; }
-            const unsigned long long seed = cur | (prev & bg);
-            unsigned long long o = cur;
-            if (__ballot(seed != cur)) {
-                o = flood_row(bg, seed, lane, WW);
-                if (lane < WW && o != cur) { out[(size_t)y * WW + lane] = o; any = true; }
+        unsigned long long nb[CHUNK], nc[CHUNK];
+        auto load1 = [&](int k0, unsigned long long *db, unsigned long long *dc) {
+#pragma unroll
+            for (int k = 0; k < CHUNK; k++) {
+                const int kk = k0 + k;
+                const int y = upw ? r.y1 - kk : r.y0 + kk;
+                const bool ok = lane < WW && kk < nrows;
+                db[k] = ok ? bgw[(size_t)y * WW + lane] : 0ull;
+                dc[k] = ok ? out[(size_t)y * WW + lane] : 0ull;
             }
-            prev = o;
+        };
+        load1(0, nb, nc);
+        for (int k0 = 0; k0 < nrows; k0 += CHUNK) {
+            unsigned long long bgc[CHUNK], curc[CHUNK];
+#pragma unroll
+            for (int k = 0; k < CHUNK; k++) { bgc[k] = nb[k]; curc[k] = nc[k]; }
+            if (k0 + CHUNK < nrows) load1(k0 + CHUNK, nb, nc);
+#pragma unroll
+            for (int k = 0; k < CHUNK; k++) {
+                const int kk = k0 + k;
+                if (kk >= nrows) break;
+                const int y = upw ? r.y1 - kk : r.y0 + kk;
+                const unsigned long long bg = bgc[k], cur = curc[k];
+                const unsigned long long seed = cur | (prev & bg);
+                unsigned long long o = cur;
+                if (__ballot(seed != cur)) {
+                    o = flood_row(bg, seed, lane, WW);
+                    if (lane < WW && o != cur) { out[(size_t)y * WW + lane] = o; any = true; }
+                }
+                prev = o;
+            }
         }
         if (!__ballot(any)) break;
     }

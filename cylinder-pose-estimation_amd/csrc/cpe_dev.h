@@ -106,6 +106,7 @@ struct MaskBuffers {
     int *lab_h, *lab_v;                       // union-find planes of the two expanded masks (read by k_lines)   // label planes / component lists of the joints and spot chains
     uint32_t *bits;
     unsigned long long *best, *best_s;
+    unsigned long long *fl_j;                 // joints chain: [n][h * ceil(w/64)] background masks, then the same of outer background
     SegRec *segs;
 };
 

@@ -43,7 +43,7 @@ struct Layout {
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_HPAR, P_HTIME, P_GMID, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_HPAR, P_HTIME, P_GMID, P_FLJ, P_COUNT
 };
 
 static_assert(P_COUNT <= 64, "Layout arrays too small");
@@ -94,6 +94,7 @@ Layout make_layout(int n, int h, int w)
     per[P_HPAR] = N * 4;
     per[P_HTIME] = N;
     per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 3 * sizeof(double);
+    per[P_FLJ] = (size_t)2 * h * ((w + 63) / 64) * sizeof(unsigned long long);   // joints chain: background / outer-background bit masks
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);
     per[P_HL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
     per[P_BL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
@@ -126,16 +127,22 @@ __global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
     if (s != CPE_ST_OK) n_pts[f] = 0;
 }
 
-// two helper streams per process (created on first use; CPE_SERIAL=1 keeps everything on the caller's stream)
+// Helper streams for the independent chains of a call: one set (three streams, their events) per device AND caller stream,
+// so two host threads -- or one thread with chunks in flight on several streams (FramePipeline(lanes=2)) -- neither share
+// nor serialise their side chains.  Created on first use, kept for the life of the process (at most SIDE_SETS caller
+// streams per device get their own set; further ones share the last).  CPE_SERIAL=1 keeps everything on the caller's stream.
 struct SideStreams {
     std::mutex mu;      // held by a caller from its fork to its join (cpe_detect_grid_batch_ex)
     bool ok = false;
+    hipStream_t key = nullptr;
+    bool used = false;
     hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
     hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, e3a = nullptr, e3b = nullptr, e3c = nullptr, e3d = nullptr;
 };
-SideStreams &side_streams()
+constexpr int SIDE_SETS = 4;
+SideStreams &side_streams(hipStream_t caller)
 {
-    static SideStreams per_dev[32];
+    static SideStreams sets[32][SIDE_SETS];
     static std::mutex mu;
     static SideStreams none;
     int dev = 0;
@@ -143,8 +150,15 @@ SideStreams &side_streams()
     const char *e = getenv("CPE_SERIAL");   // looked at on every call: a profiling pass can switch the overlap off
     if (e && e[0] == '1') return none;
     std::lock_guard<std::mutex> lk(mu);
-    SideStreams &X = per_dev[dev];
-    if (!X.s1 && !X.ok) {
+    int slot = SIDE_SETS - 1;
+    for (int k = 0; k < SIDE_SETS; k++) {
+        if (sets[dev][k].used && sets[dev][k].key == caller) { slot = k; break; }
+        if (!sets[dev][k].used) { slot = k; break; }
+    }
+    SideStreams &X = sets[dev][slot];
+    if (!X.used) {
+        X.used = true;
+        X.key = caller;
         bool good = hipStreamCreateWithFlags(&X.s1, hipStreamNonBlocking) == hipSuccess &&
                     hipStreamCreateWithFlags(&X.s2, hipStreamNonBlocking) == hipSuccess &&
                     hipStreamCreateWithFlags(&X.s3, hipStreamNonBlocking) == hipSuccess &&
@@ -233,12 +247,13 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
     M.lab_p = PL(int, P_LABP); M.lab_s = PL(int, P_LABS); M.roots_p = PL(int, P_ROOTSP); M.roots_s = PL(int, P_ROOTSS);
     M.best_s = PL(unsigned long long, P_BEST2);
+    M.fl_j = PL(unsigned long long, P_FLJ);
     // three chains that only meet in masks_stage: ridge mask -> line masks -> joints (stream 1), saturated spot
     // (stream 2), region (the caller's stream).  The side chains are mostly ALU / latency bound and fill the CUs the
     // region stage's serial kernels leave idle.  The helper streams and their events are per device and shared by all
     // callers: the enqueue below (fork .. join, host side only, microseconds per kernel) runs under the device's mutex,
     // so two host threads never interleave their forks and joins.
-    SideStreams &X = side_streams();
+    SideStreams &X = side_streams(s);
     std::unique_lock<std::mutex> lk(X.mu, std::defer_lock);
     if (X.ok) lk.lock();
     bool forked = false;

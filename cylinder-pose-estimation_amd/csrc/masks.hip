@@ -1114,7 +1114,11 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st,
         }
     }
     CPE_CHECK_LAUNCH("joints_mask_stage");
-    return ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab_p, B.roots_p, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 1);
+    int rc;
+    if ((rc = ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab_p, B.roots_p, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 1)) != CPE_OK) return rc;
+    // RETR_EXTERNAL (:1817): outer background of the joints mask (whole frame), on this chain, beside the region stage
+    const size_t fl_words = (size_t)h * ((w + 63) / 64);
+    return outside_flood(B.joints_mask, n, h, w, st, 0, B.fl_j, B.fl_j + (size_t)n * fl_words, fl_words, s);
 }
 
 // a-5 head: saturated spot -> circle_mask, r0 (depends on the grey frame only: own stream)
@@ -1152,10 +1156,9 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     const size_t bit_words = (size_t)n * h * bit_row_words(w);
     const size_t fl_words = (size_t)h * bit_row_words(w) / 2;          // u64 words per frame of one flood plane
     auto fl_plane = [&](int k) { return reinterpret_cast<unsigned long long *>(B.bits + (size_t)(2 + k) * ((bit_words + 1) & ~(size_t)1)); };
-    // joints
-    if ((rc = outside_flood(B.joints_mask, n, h, w, st, 0, fl_plane(0), fl_plane(1), fl_words, s)) != CPE_OK) return rc;
+    // joints (their outer-background mask comes from the joints chain)
     CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp,
-                (const unsigned long long *)fl_plane(1), fl_words);
+                (const unsigned long long *)(B.fl_j + (size_t)n * h * ((w + 63) / 64)), (size_t)h * ((w + 63) / 64));
     CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
     // a-5 tail, a-6 and the labelling of the expanded masks, once per line direction.  The two directions share
     // nothing but their inputs: the vertical one runs on the helper stream (if any) with the spot chain's label plane.
