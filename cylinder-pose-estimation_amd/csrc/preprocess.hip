@@ -67,11 +67,13 @@ struct GView {
     }
 };
 
-// A workgroup is persistent: it walks tiles tile0, tile0 + 1, ... of its share.  The shares are laid out so that the
-// workgroups of one XCD (blockIdx % 8 under round-robin placement: speed only) work on neighbouring tiles at the same time
-// and find each other's halos in their L2.  The gray window of the NEXT tile is requested from HBM while the current tile
-// is in its f64 phases (the window buffer is free after phase B) and stored into LDS late in the iteration, so its latency
-// is hidden behind the arithmetic instead of being waited for with one workgroup per CU and nothing else to run.
+// A workgroup works through RUN consecutive tiles (same frame row mostly: neighbouring tiles share halo columns in L1 / L2).
+// The gray window of the NEXT tile is requested from HBM while the current tile is in its f64 phases (the window buffer is
+// free after phase B) and stored into LDS late in the iteration, so its latency hides behind the arithmetic instead of
+// being waited for with one workgroup per CU and nothing else to run.  Runs are short on purpose: a grid of fully persistent
+// workgroups (one per CU for the whole launch) was 8 % faster alone but starved the other chains of the call, which share
+// the GPU with this kernel through the dispatcher's interleaving of workgroups.
+constexpr int RUN = 8;
 constexpr int A_DW = AH * (AW / 4);                 // dwords of the gray window
 constexpr int A_PER = (A_DW + NT - 1) / NT;         // per thread
 __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ gray, int h, int w,
@@ -81,11 +83,9 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
     __shared__ Smem s;
     const int tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
-    // this workgroup's tiles: XCD x = blockIdx % 8 owns the contiguous range [x * per_xcd, (x + 1) * per_xcd); its workgroups
-    // (slot j of nslot) take tiles j, j + nslot, ... of that range
-    const int nslot = gridDim.x / 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    const long long per_xcd = (total_tiles + 7) / 8;
-    const long long range_lo = xcd * per_xcd, range_hi = range_lo + per_xcd < total_tiles ? range_lo + per_xcd : total_tiles;
+    const int nslot = 1;
+    const long long range_lo = (long long)blockIdx.x * RUN, slot = 0;
+    const long long range_hi = range_lo + RUN < total_tiles ? range_lo + RUN : total_tiles;
     auto fast_tile = [&](long long tix, const uint8_t *&img_out, int &gx0_out, int &gy0_out) -> bool {
         const int frame = (int)(tix / tiles), t = (int)(tix - (long long)frame * tiles);
         gx0_out = (t % tiles_x) * TX; gy0_out = (t / tiles_x) * TY;
@@ -380,16 +380,7 @@ extern "C" int32_t cpe_preprocess_batch(const uint8_t *gray, int32_t n, int32_t 
     if (n == 0) return CPE_OK;
     int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
     const long long blocks = (long long)n * tiles_x * tiles_y;
-    // persistent workgroups, one per CU (the tile buffers take the CU's LDS); a multiple of 8 so that every XCD gets the same
-    static int cu_count[64] = {0};                    // per device, filled on first use (identical values if threads race)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cu_count[dev] == 0) {
-        int v = 0;
-        cu_count[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) ? v / 8 * 8 : 256;
-    }
-    const int cus = cu_count[dev];
-    const unsigned grid = (unsigned)std::min<long long>(cus, (blocks + 7) / 8 * 8);
+    const unsigned grid = (unsigned)((blocks + RUN - 1) / RUN);
     CPE_LAUNCH_BEGIN();
     CPE_KLAUNCH(k_preprocess, dim3(grid), dim3(NT), 0, (hipStream_t)stream, gray, h, w,
                        tiles_x, tiles_y, blocks, mask);

@@ -110,3 +110,20 @@ def test_bench_under_torchrun_form():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert out['n_gpus'] == 2 and out['rows'] == 9 and out['checksum'] == 36.0
+
+
+def test_bench_batch_does_not_depend_on_the_sharding():
+    """strong scaling shards THE batch: the frames a rank renders for its block are the frames of the one-rank run"""
+    sys.path.insert(0, ROOT)
+    import bench
+    import cpe_amd
+    from cpe_amd import synth
+    old = bench.H, bench.W
+    bench.H, bench.W = 96, 128
+    try:
+        full = bench.make_frames(synth, torch, 0, 20, 6, 'cpu')
+        parts = [bench.make_frames(synth, torch, lo, hi, 6, 'cpu') for lo, hi in ((0, 7), (7, 14), (14, 20))]
+        assert torch.equal(torch.cat([p[1] for p in parts]), full[1]) and torch.equal(torch.cat([p[2] for p in parts]), full[2])
+        assert not torch.equal(full[1][6], full[1][0])            # frame 6 = scene 0 with its own noise
+    finally:
+        bench.H, bench.W = old
