@@ -1039,9 +1039,43 @@ __global__ __launch_bounds__(64) void k_fit_ransac(const double *__restrict__ X,
 
 }  // namespace
 
+namespace {
+// triangulate(matchedPoints1, matchedPoints2, stereoParams) for n frames of already matched pairs (fitSingleCylinder.m:15-17):
+// one wavefront per frame, one lane per point; meanError through the same 64-lane tree as everywhere else
+__global__ __launch_bounds__(64) void k_triangulate(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                    const int *__restrict__ cnt, const double *__restrict__ K1,
+                                                    const double *__restrict__ K2, const double *__restrict__ T21,
+                                                    double *__restrict__ o_X, double *__restrict__ o_err, double *__restrict__ o_mean_err)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int m = min(max(cnt[f], 0), MAXP);
+    double P1[12], P2[12];
+    {
+        const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        double k1[9], k2[9], tt[16];
+        for (int k = 0; k < 9; k++) { k1[k] = K1[k]; k2[k] = K2[k]; }
+        for (int k = 0; k < 16; k++) tt[k] = T21[k];
+        make_P(k1, I4, P1);
+        make_P(k2, tt, P2);
+    }
+    double es = 0.0;
+    for (int k = lane; k < m; k += 64) {
+        const size_t o = (size_t)f * MAXP + k;
+        double X[3], e;
+        triangulate_one(P1, P2, p1[2 * o], p1[2 * o + 1], p2[2 * o], p2[2 * o + 1], X, e);
+        o_X[3 * o] = X[0]; o_X[3 * o + 1] = X[1]; o_X[3 * o + 2] = X[2];
+        o_err[o] = e;
+        es = es + e;
+    }
+    es = wave_sum(es);
+    if (lane == 0) o_mean_err[f] = m > 0 ? es / (double)m : 0.0;
+}
+}  // namespace
+
 extern "C" size_t cpe_fit_workspace_bytes(int32_t n)
 {
-    return (size_t)(n > 0 ? n : 0) * 2 * TBL * TBL * sizeof(int);
+    // index tables of the selector + room for the by-products cpe_choose_idx_batch does not hand out (X, err, mean_err)
+    return (size_t)(n > 0 ? n : 0) * (2 * TBL * TBL * sizeof(int) + (size_t)MAXP * 4 * sizeof(double) + sizeof(double));
 }
 
 extern "C" int32_t cpe_select_triangulate_batch(const double *xy1, const int32_t *id1, const int32_t *cnt1,
@@ -1067,6 +1101,37 @@ extern "C" int32_t cpe_select_triangulate_batch(const double *xy1, const int32_t
     CPE_KLAUNCH(k_select_triangulate, dim3(n), dim3(64), SEL_LDS_BYTES, (hipStream_t)stream, xy1, id1, cnt1, xy2, id2, cnt2,
                        K1, K2, T21, selector, patch, th, (int *)ws, p1, p2, idx, X, err, m, mean_err, flags);
     CPE_CHECK_LAUNCH("k_select_triangulate");
+    return CPE_OK;
+}
+
+extern "C" int32_t cpe_choose_idx_batch(const double *xy1, const int32_t *id1, const int32_t *cnt1, const double *xy2,
+                                        const int32_t *id2, const int32_t *cnt2, int32_t n, const double *K1, const double *K2,
+                                        const double *T21, int32_t patch, double th, void *ws, size_t ws_bytes, double *p1,
+                                        double *p2, int32_t *idx, int32_t *m, int32_t *flags, void *stream)
+{
+    CPE_CHECK_ARG(n >= 0, "cpe_choose_idx_batch: n < 0");
+    if (n == 0) return CPE_OK;
+    if (!ws || ws_bytes < cpe_fit_workspace_bytes(n)) {
+        cpe::set_error("cpe_choose_idx_batch: workspace too small (%zu < %zu)", ws_bytes, cpe_fit_workspace_bytes(n));
+        return CPE_ERR_WORKSPACE;
+    }
+    // the selector triangulates every candidate anyway: its points and errors land in the workspace behind the index tables
+    double *X = reinterpret_cast<double *>(static_cast<char *>(ws) + (size_t)n * 2 * TBL * TBL * sizeof(int));
+    double *err = X + (size_t)n * MAXP * 3, *mean_err = err + (size_t)n * MAXP;
+    return cpe_select_triangulate_batch(xy1, id1, cnt1, xy2, id2, cnt2, n, K1, K2, T21, CPE_SEL_CHOOSE_IDX, patch, th, ws, ws_bytes,
+                                        p1, p2, idx, X, err, m, mean_err, flags, stream);
+}
+
+extern "C" int32_t cpe_triangulate_batch(const double *p1, const double *p2, const int32_t *cnt, int32_t n, const double *K1,
+                                         const double *K2, const double *T21, double *X, double *err, double *mean_err,
+                                         void *stream)
+{
+    CPE_CHECK_ARG(p1 && p2 && cnt && K1 && K2 && T21 && X && err && mean_err, "cpe_triangulate_batch: null pointer");
+    CPE_CHECK_ARG(n >= 0, "cpe_triangulate_batch: n < 0");
+    if (n == 0) return CPE_OK;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_triangulate, dim3(n), dim3(64), 0, (hipStream_t)stream, p1, p2, cnt, K1, K2, T21, X, err, mean_err);
+    CPE_CHECK_LAUNCH("k_triangulate");
     return CPE_OK;
 }
 

@@ -69,6 +69,40 @@ def select_triangulate_batch(gp1: GridTables, gp2: GridTables, K1, K2, T21, sele
     return dict(p1=p1, p2=p2, idx=idx, pts3=X, err=err, m=m, mean_err=me, flags=flags, _ws=ws)
 
 
+def choose_idx_batch(gp1: GridTables, gp2: GridTables, K1, K2, T21, patch=3, th=0.3):
+    """[cgp1, cgp2] = chooseIdx(gp1, gp2, imgInfo, stereoParams, patch, th) (chooseIdx.m; fitSingleCylinder.m:12) for a batch:
+    dict(p1, p2 f64[n,MAXP,2], idx i32[n,MAXP,2], m i32[n], flags i32[n])"""
+    L = _lib.load()
+    dev = gp1.xy.device
+    n = gp1.cnt.shape[0]
+    K1 = _dev3(K1, dev, (9,)); K2 = _dev3(K2, dev, (9,)); T21 = _dev3(T21, dev, (16,))
+    ws_bytes = L.cpe_fit_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+    p1 = torch.zeros((n, MAXP, 2), dtype=torch.float64, device=dev); p2 = torch.zeros_like(p1)
+    idx = torch.zeros((n, MAXP, 2), dtype=torch.int32, device=dev)
+    m = torch.zeros(n, dtype=torch.int32, device=dev); flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    _lib.check(L.cpe_choose_idx_batch(gp1.xy.data_ptr(), gp1.id.data_ptr(), gp1.cnt.data_ptr(), gp2.xy.data_ptr(), gp2.id.data_ptr(),
+                                      gp2.cnt.data_ptr(), n, K1.data_ptr(), K2.data_ptr(), T21.data_ptr(), patch, th, ws.data_ptr(),
+                                      ws_bytes, p1.data_ptr(), p2.data_ptr(), idx.data_ptr(), m.data_ptr(), flags.data_ptr(), _stream()),
+               'cpe_choose_idx_batch')
+    return dict(p1=p1, p2=p2, idx=idx, m=m, flags=flags, _ws=ws)
+
+
+def triangulate_batch(p1, p2, cnt, K1, K2, T21):
+    """[worldPoints, reprojectionErrors] = triangulate(cgp1, cgp2, stereoParams) + meanError (fitSingleCylinder.m:15-17):
+    p1, p2 f64[n,MAXP,2], cnt i32[n] -> dict(pts3 f64[n,MAXP,3], err f64[n,MAXP], mean_err f64[n])"""
+    L = _lib.load()
+    dev = p1.device
+    n = cnt.shape[0]
+    K1 = _dev3(K1, dev, (9,)); K2 = _dev3(K2, dev, (9,)); T21 = _dev3(T21, dev, (16,))
+    X = torch.zeros((n, MAXP, 3), dtype=torch.float64, device=dev)
+    err = torch.zeros((n, MAXP), dtype=torch.float64, device=dev); me = torch.zeros(n, dtype=torch.float64, device=dev)
+    _lib.check(L.cpe_triangulate_batch(p1.contiguous().data_ptr(), p2.contiguous().data_ptr(), cnt.data_ptr(), n, K1.data_ptr(),
+                                       K2.data_ptr(), T21.data_ptr(), X.data_ptr(), err.data_ptr(), me.data_ptr(), _stream()),
+               'cpe_triangulate_batch')
+    return dict(pts3=X, err=err, mean_err=me)
+
+
 FIT_NELDER_MEAD, FIT_LM = 0, 1
 
 

@@ -43,6 +43,9 @@ _SIGS = {
     'cpe_fit_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'cpe_select_triangulate_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 +
                                      [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
+    'cpe_choose_idx_batch': (C.c_int32, [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_double, C.c_void_p, C.c_size_t] +
+                             [C.c_void_p] * 6),
+    'cpe_triangulate_batch': (C.c_int32, [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 7),
     'cpe_multi_frame_terms': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     'cpe_fit_cylinder_ransac_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p] +
                                       [C.c_void_p] * 9),

@@ -203,6 +203,21 @@ CPE_API int32_t cpe_select_triangulate_batch(const double *xy1, const int32_t *i
                                              double *p2, int32_t *idx, double *X, double *err, int32_t *m,
                                              double *mean_err, int32_t *flags, void *stream);
 
+/* The two halves of the above on their own (SURVEY 8b lists them as separate entry points).
+ * cpe_choose_idx_batch: [cgp1, cgp2] = chooseIdx(gp1, gp2, imgInfo, stereoParams, patch, th) (chooseIdx.m:1-105; call at
+ *   fitSingleCylinder.m:12 with patch 3, th 0.3), fallback to findGridCorrespondences included (flags).  Outputs p1, p2, idx,
+ *   m, flags as above; ws as above.
+ * cpe_triangulate_batch: [worldPoints, reprojectionErrors] = triangulate(cgp1, cgp2, stereoParams) for pairs that are already
+ *   matched, and meanError = mean(reprojectionErrors) (fitSingleCylinder.m:15-17).  p1, p2 f64[n,CPE_MAXP,2], cnt i32[n] ->
+ *   X f64[n,CPE_MAXP,3] (camera-1 frame), err f64[n,CPE_MAXP], mean_err f64[n]. */
+CPE_API int32_t cpe_choose_idx_batch(const double *xy1, const int32_t *id1, const int32_t *cnt1, const double *xy2,
+                                     const int32_t *id2, const int32_t *cnt2, int32_t n, const double *K1, const double *K2,
+                                     const double *T21, int32_t patch, double th, void *ws, size_t ws_bytes, double *p1,
+                                     double *p2, int32_t *idx, int32_t *m, int32_t *flags, void *stream);
+CPE_API int32_t cpe_triangulate_batch(const double *p1, const double *p2, const int32_t *cnt, int32_t n, const double *K1,
+                                      const double *K2, const double *T21, double *X, double *err, double *mean_err,
+                                      void *stream);
+
 typedef struct CpeFitParams {
     double tol_x;          /* fminsearch TolX  (fitCylinderWPts3.m:33: 1e-5) */
     double tol_f;          /* fminsearch TolFun (1e-5) */

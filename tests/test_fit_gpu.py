@@ -126,3 +126,33 @@ def test_lm_mode_bit_exact_and_close_to_nelder_mead(cpe, orc, gpu):
             close += 1
         assert int(lm['iters'][i, 0]) < 50
     assert close >= 6, close
+
+
+@pytest.mark.gpu
+def test_choose_idx_and_triangulate_as_separate_entry_points(cpe, orc, gpu):
+    """SURVEY 8b lists chooseIdx and triangulate as entry points of their own: cpe_choose_idx_batch selects (with the fallback
+    join), cpe_triangulate_batch takes pairs that are already matched -- what fitSingleCylinder.m:12 and :15-17 do in turn.
+    Both equal the oracle and the merged cpe_select_triangulate_batch bit for bit."""
+    from cpe_amd import fit
+    t1, t2, K1, K2, T21, fp, sc = make_tables(7, 5, h=1200, w=1920, outlier=0.05)
+    t1.append(t1[0][:0]); t2.append(t2[0])                       # an empty left table: m = 0
+    g1 = fit.GridTables.from_lists(t1, gpu); g2 = fit.GridTables.from_lists(t2, gpu)
+    sel = fit.choose_idx_batch(g1, g2, K1, K2, T21, 3, 0.3)
+    tri = fit.triangulate_batch(sel['p1'], sel['p2'], sel['m'], K1, K2, T21)
+    both = fit.select_triangulate_batch(g1, g2, K1, K2, T21, selector=0, th=0.3)
+    torch.cuda.synchronize()
+    for i in range(len(t1)):
+        m = int(sel['m'][i])
+        assert m == int(both['m'][i])
+        if len(t1[i]) == 0:
+            assert m == 0 and float(tri['mean_err'][i]) == 0.0
+            continue
+        c1, c2, idx, fb = orc.choose_idx(t1[i], t2[i], K1, K2, T21, 3, 0.3)
+        assert m == len(c1) and np.array_equal(sel['p1'][i, :m].cpu().numpy(), c1) and np.array_equal(sel['p2'][i, :m].cpu().numpy(), c2)
+        assert np.array_equal(sel['idx'][i, :m].cpu().numpy(), idx) and bool(int(sel['flags'][i]) & 1) == fb
+        X, err = orc.triangulate(c1, c2, K1, K2, T21)
+        assert np.array_equal(tri['pts3'][i, :m].cpu().numpy(), X)
+        assert np.array_equal(tri['err'][i, :m].cpu().numpy(), err)
+        assert np.array_equal(tri['pts3'][i, :m].cpu().numpy(), both['pts3'][i, :m].cpu().numpy())
+        assert float(tri['mean_err'][i]) == float(both['mean_err'][i])
+    assert int(sel['m'].max()) > 100
