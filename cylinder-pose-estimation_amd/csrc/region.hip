@@ -1193,12 +1193,19 @@ __global__ __launch_bounds__(256) void k_discs(FrameState *__restrict__ st, cons
 // contourArea of every external contour of the disc union; keep the largest (first in OpenCV order on ties)
 __global__ __launch_bounds__(64) void k_region_area(const uint32_t *__restrict__ ext_bits, int h, int w,
                                                     const int *__restrict__ roots, FrameState *__restrict__ st,
-                                                    unsigned long long *__restrict__ best)
+                                                    unsigned long long *__restrict__ best, int single_is_positive)
 {
     __shared__ unsigned long long s_win[BW_ROWS * 64];
     const int f = blockIdx.y;
     const int ncomp = min(st[f].n_roots, MAXROOTS);
     const int ws = bit_row_words(w);
+    if (single_is_positive && ncomp == 1) {
+        // the usual case of the disc union: one component, so there is nothing to compare and its 3000-step border (one
+        // lane, ~1.7 us per step: 5 ms on the critical path of a call) need not be walked.  Its area is positive: a
+        // union of filled discs of radius >= 4.
+        if (blockIdx.x == 0 && threadIdx.x == 0) best[f] = (1ull << 24) | (unsigned long long)(roots[(size_t)f * MAXROOTS] & 0xFFFFFF);
+        return;
+    }
     for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {   // components in turns, one per lane
         const int root = roots[(size_t)f * MAXROOTS + k];
         BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
@@ -1280,12 +1287,52 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
     int *lo = in_lds ? s_lo : lohi + (size_t)f * 2 * w, *hi = in_lds ? s_hi : lohi + (size_t)f * 2 * w + w;
     int *hp = in_lds ? s_hp : hull + (size_t)f * 4 * w;
     for (int x = t; x < w; x += 256) { lo[x] = INT_MAX; hi[x] = INT_MIN; }
+    __shared__ int s_box[4];
+    if (t == 0) { s_box[0] = INT_MAX; s_box[1] = INT_MIN; s_box[2] = INT_MAX; s_box[3] = INT_MIN; }
     __syncthreads();
+    const int ws = bit_row_words(w);
+    // One component in the mask (the usual case): the column extents of the contour are the column extents of the mask (the
+    // top / bottom pixel of a column has only background above / below it up to the frame border, so it lies on the outer
+    // border), found by all threads from the bit plane instead of one lane walking the border.
+    const bool single = S.n_roots == 1;
+    if (single) {
+        const uint32_t *plane = ext_bits + (size_t)f * h * ws;
+        const int nwc = (w + 31) >> 5;              // word columns that hold pixels: words 1 .. nwc of a row
+        constexpr int SEG = 4;                      // row segments per word column
+        for (int item = t; item < nwc * SEG; item += 256) {
+            const int j = item % nwc, seg = item / nwc;
+            const int y0 = (int)((long long)h * seg / SEG), y1 = (int)((long long)h * (seg + 1) / SEG);
+            uint32_t seen = 0;
+            for (int y = y0; y < y1; y++) {
+                const uint32_t v = plane[(size_t)y * ws + 1 + j];
+                uint32_t nw = v & ~seen;
+                seen |= v;
+                while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMin(&lo[32 * j + b], y); }
+            }
+            seen = 0;
+            for (int y = y1 - 1; y >= y0; y--) {
+                const uint32_t v = plane[(size_t)y * ws + 1 + j];
+                uint32_t nw = v & ~seen;
+                seen |= v;
+                while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMax(&hi[32 * j + b], y); }
+            }
+        }
+        __syncthreads();
+        int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
+        for (int x = t; x < w; x += 256) {
+            if (lo[x] == INT_MAX) continue;
+            mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, lo[x]); mxy = max(mxy, hi[x]);
+        }
+        if (mxx >= 0) { atomicMin(&s_box[0], mnx); atomicMax(&s_box[1], mxx); atomicMin(&s_box[2], mny); atomicMax(&s_box[3], mxy); }
+        __syncthreads();
+    }
     if (t == 0) {
-        const int ws = bit_row_words(w);
-        BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win};
         HullVisitor hv{lo, hi};
-        trace_border(nz, root % w, root / w, false, hv, 8 * (w + h) + (1 << 20));
+        if (single) { hv.minx = s_box[0]; hv.maxx = s_box[1]; hv.miny = s_box[2]; hv.maxy = s_box[3]; }
+        else {
+            BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win};
+            trace_border(nz, root % w, root / w, false, hv, 8 * (w + h) + (1 << 20));
+        }
         S.rect[0] = hv.minx; S.rect[1] = hv.miny; S.rect[2] = hv.maxx - hv.minx + 1; S.rect[3] = hv.maxy - hv.miny + 1;
         // monotone chain over columns; points sorted by (x,y): per column first lo then hi
         int k = 0;
@@ -1536,7 +1583,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_discs, dim3(frame_waves(n, 4, MAXG / 4), n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
     if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     if ((rc = build_bitplanes(B.ext, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
-    CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
+    CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best, 1);
     CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
     return CPE_OK;
@@ -1571,7 +1618,7 @@ int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuf
         if (round == 1) CPE_KLAUNCH(k_best_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best);
         if ((rc = ccl_run(img, n, h, w, thr, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(img, n, h, w, thr, 0, 1, B.bits, s)) != CPE_OK) return rc;
-        CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best);
+        CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best, 0);
         CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, dst);
         if (round == 0) {
             const int tiles_x = (w + 63) / 64, tiles_y = (h + 31) / 32;

@@ -19,13 +19,10 @@ def init_from_env(backend=None, device_index=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        kw = {}
         if backend == 'nccl':
-            idx = local if device_index is None else device_index
-            torch.cuda.set_device(idx)
-            kw['device_id'] = torch.device(f'cuda:{idx}')     # binds the communicator to this rank's GPU (eager init)
+            torch.cuda.set_device(local if device_index is None else device_index)   # the communicator binds to the current device
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10), **kw)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     return rank, local, world
 
 
@@ -86,7 +83,10 @@ def gather_records(rec, total=None):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device):
