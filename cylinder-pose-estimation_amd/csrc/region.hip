@@ -1302,19 +1302,30 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
         for (int item = t; item < nwc * SEG; item += 256) {
             const int j = item % nwc, seg = item / nwc;
             const int y0 = (int)((long long)h * seg / SEG), y1 = (int)((long long)h * (seg + 1) / SEG);
+            // rows in batches of 8: the loads of a batch are independent and in flight together
             uint32_t seen = 0;
-            for (int y = y0; y < y1; y++) {
-                const uint32_t v = plane[(size_t)y * ws + 1 + j];
-                uint32_t nw = v & ~seen;
-                seen |= v;
-                while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMin(&lo[32 * j + b], y); }
+            for (int yb = y0; yb < y1; yb += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = yb + k < y1 ? plane[(size_t)(yb + k) * ws + 1 + j] : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    uint32_t nw = v[k] & ~seen;
+                    seen |= v[k];
+                    while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMin(&lo[32 * j + b], yb + k); }
+                }
             }
             seen = 0;
-            for (int y = y1 - 1; y >= y0; y--) {
-                const uint32_t v = plane[(size_t)y * ws + 1 + j];
-                uint32_t nw = v & ~seen;
-                seen |= v;
-                while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMax(&hi[32 * j + b], y); }
+            for (int yb = y1 - 1; yb >= y0; yb -= 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = yb - k >= y0 ? plane[(size_t)(yb - k) * ws + 1 + j] : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    uint32_t nw = v[k] & ~seen;
+                    seen |= v[k];
+                    while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMax(&hi[32 * j + b], yb - k); }
+                }
             }
         }
         __syncthreads();
@@ -1369,39 +1380,64 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
         int a = (e + nh - 1) % nh;
         dev_line(out, h, w, hp[2 * a], hp[2 * a + 1], hp[2 * e], hp[2 * e + 1]);
     }
-    // scan-line fill (FillEdgeCollection): x in 16.16, left ceil / right floor, rows [ymin, ymax)
+    // scan-line fill (FillEdgeCollection): x in 16.16, left ceil / right floor, rows [ymin, ymax).
+    // 256 rows at a time: a thread finds the spans of its row (edge crossings, sorted), then the wavefronts write the rows
+    // with the lanes across x (16-byte stores where the row allows) -- one thread storing its row byte by byte, every lane
+    // on a row of its own, was most of this kernel's time.
     const int ymin = S.rect[1], ymax = min(S.rect[1] + S.rect[3] - 1, h);
-    for (int y = ymin + t; y < ymax; y += 256) {
-        long long xs[8];
-        int na = 0;
-        for (int e = 0; e < nh && na < 8; e++) {
-            int a = (e + nh - 1) % nh;
-            long long p0x = (long long)hp[2 * a] << 16, p1x = (long long)hp[2 * e] << 16;
-            int p0y = hp[2 * a + 1], p1y = hp[2 * e + 1];
-            if (p0y == p1y) continue;
-            int ey0, ey1;
-            long long ex;
-            if (p0y < p1y) { ey0 = p0y; ey1 = p1y; ex = p0x; }
-            else { ey0 = p1y; ey1 = p0y; ex = p1x; }
-            if (!(ey0 <= y && y < ey1)) continue;
-            long long dx = (p1x - p0x) / (p1y - p0y);
-            xs[na++] = ex + (long long)(y - ey0) * dx;
-        }
-        for (int a = 1; a < na; a++) {
-            long long kx = xs[a];
-            int b = a - 1;
-            while (b >= 0 && xs[b] > kx) { xs[b + 1] = xs[b]; b--; }
-            xs[b + 1] = kx;
-        }
-        if (y < 0) continue;
-        for (int a = 0; a + 1 < na; a += 2) {
-            int x1 = (int)((xs[a] + 65535) >> 16), x2 = (int)(xs[a + 1] >> 16);
-            if (x1 < w && x2 >= 0) {
-                x1 = max(x1, 0);
-                x2 = min(x2, w - 1);
-                for (int x = x1; x <= x2; x++) out[(size_t)y * w + x] = 255;
+    __shared__ int s_span[256][8];
+    __shared__ int s_nsp[256];
+    const bool al16 = (w & 15) == 0 && (((size_t)out) & 15) == 0;
+    for (int yc = ymin; yc < ymax; yc += 256) {
+        const int y = yc + t;
+        int nsp = 0;
+        if (y < ymax) {
+            long long xs[8];
+            int na = 0;
+            for (int e = 0; e < nh && na < 8; e++) {
+                int a = (e + nh - 1) % nh;
+                long long p0x = (long long)hp[2 * a] << 16, p1x = (long long)hp[2 * e] << 16;
+                int p0y = hp[2 * a + 1], p1y = hp[2 * e + 1];
+                if (p0y == p1y) continue;
+                int ey0, ey1;
+                long long ex;
+                if (p0y < p1y) { ey0 = p0y; ey1 = p1y; ex = p0x; }
+                else { ey0 = p1y; ey1 = p0y; ex = p1x; }
+                if (!(ey0 <= y && y < ey1)) continue;
+                long long dx = (p1x - p0x) / (p1y - p0y);
+                xs[na++] = ex + (long long)(y - ey0) * dx;
+            }
+            for (int a = 1; a < na; a++) {
+                long long kx = xs[a];
+                int b = a - 1;
+                while (b >= 0 && xs[b] > kx) { xs[b + 1] = xs[b]; b--; }
+                xs[b + 1] = kx;
+            }
+            if (y >= 0) {
+                for (int a = 0; a + 1 < na; a += 2) {
+                    int x1 = (int)((xs[a] + 65535) >> 16), x2 = (int)(xs[a + 1] >> 16);
+                    if (x1 < w && x2 >= 0) {
+                        s_span[t][2 * nsp] = max(x1, 0);
+                        s_span[t][2 * nsp + 1] = min(x2, w - 1);
+                        nsp++;
+                    }
+                }
             }
         }
+        s_nsp[t] = nsp;
+        __syncthreads();
+        const int lane = t & 63, wave = t >> 6;
+        for (int rr = wave; rr < 256 && yc + rr < ymax; rr += 4) {
+            uint8_t *row = out + (size_t)(yc + rr) * w;
+            for (int q = 0; q < s_nsp[rr]; q++) {
+                const int x1 = s_span[rr][2 * q], x2 = s_span[rr][2 * q + 1];
+                for (int xb = (x1 & ~15) + 16 * lane; xb <= x2; xb += 16 * 64) {
+                    if (al16 && xb >= x1 && xb + 15 <= x2) *reinterpret_cast<uint4 *>(row + xb) = make_uint4(~0u, ~0u, ~0u, ~0u);
+                    else for (int x = max(xb, x1); x <= min(xb + 15, x2); x++) row[x] = 255;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
