@@ -294,7 +294,7 @@ def run_rank(args):
         cpe_amd.lib.load()                               # no CPU fallback: fail loudly
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
     if args.chunk <= 0:
-        args.chunk = 256 if H * W <= 1920 * 1200 else 64
+        args.chunk = 160 if H * W <= 1920 * 1200 else 40   # x lanes x 2 images x ~340 MB (1920x1200) of workspace
     if scaling == 'strong':
         total = args.frames
         lo, hi = D.shard_range(total, rank, world)
@@ -412,7 +412,7 @@ def run_rank(args):
                             f'(BASELINE.json configs[{2 if world == 1 else 3}])')
             out['config'] = dict(workload=f'{total}-frame {W}x{H} stereo batch' + (f' sharded x{world}' if world > 1 else '') +
                                           f', full detect (both images) + chooseIdx + triangulate + ' + fit_txt,
-                                 frames_total=total, frames_per_gpu=F, chunk=min(args.chunk, F), unique_scenes=U, fit_mode=args.fit_mode,
+                                 frames_total=total, frames_per_gpu=F, chunk=min(args.chunk, F), lanes=args.lanes, unique_scenes=U, fit_mode=args.fit_mode,
                                  parallelism=f'contiguous frame shards x{world} (dist.shard_range), no data-path collective, '
                                              f'one all_gather of 128-B pose records per step', backend=backend, ranks=world)
             out.update(frames_ok_fraction=ok, mean_points_per_frame=float(n_pts.float().mean().item()),
@@ -441,8 +441,10 @@ def main():
     ap.add_argument('--scaling', choices=['strong', 'weak'], default=None,
                     help='default: strong for N > 1 (BASELINE.json configs[3]: the 4096-frame batch sharded N x)')
     ap.add_argument('--chunk', type=int, default=0,
-                    help='stereo frames per kernel batch (workspace size); 0 = 256 at 1920x1200, 64 at 3840x2160')
-    ap.add_argument('--lanes', type=int, default=1, help='chunks in flight, each on its own HIP stream with its own workspace')
+                    help='stereo frames per kernel batch (workspace size); 0 = 160 at 1920x1200, 40 at 3840x2160 (x --lanes in flight)')
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='chunks in flight, each on its own HIP stream with its own workspace: the narrow tail of one chunk (fragments, '
+                         'lines: one workgroup per image) runs beside the wide kernels of the next')
     ap.add_argument('--unique', type=int, default=256, help='distinct rendered scenes (cycled with fresh noise)')
     ap.add_argument('--fit-mode', choices=['nm', 'lm'], default='nm',
                     help='nm = fminsearch clone (reference behaviour, default); lm = Levenberg-Marquardt fast mode')

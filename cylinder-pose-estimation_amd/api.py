@@ -29,15 +29,29 @@ _STATE_FIELDS = ['status', 'rect0', 'rect1', 'rect2', 'rect3', 'r0', 'spot0', 's
 
 
 class DetectWorkspace:
-    """device scratch for cpe_detect_grid_batch, reusable across calls with the same (n, h, w)"""
+    """device scratch for cpe_detect_grid_batch, reusable across calls with the same frame size and up to n frames (a
+    smaller batch, e.g. the ragged last chunk of a run, is laid out inside the same buffer)"""
 
     def __init__(self, n, h, w, device):
         self.n, self.h, self.w = n, h, w
+        self.capacity_n = n
         L = _lib.load()
         self.bytes = L.cpe_detect_workspace_bytes(n, h, w)
+        self.capacity = self.bytes
         self.buf = torch.empty(self.bytes + 256, dtype=torch.uint8, device=device)
         off = (-self.buf.data_ptr()) % 256
         self.view = self.buf[off:off + self.bytes]
+
+    def fits(self, n, h, w):
+        return (h, w) == (self.h, self.w) and n <= self.capacity_n and \
+            _lib.load().cpe_detect_workspace_bytes(n, h, w) <= self.capacity
+
+    def use(self, n):
+        """lay the buffer out for a batch of n frames (n <= the n it was made for)"""
+        if n != self.n:
+            self.n = n
+            self.bytes = _lib.load().cpe_detect_workspace_bytes(n, self.h, self.w)
+        return self
 
     def plane(self, name):
         """intermediate of the last call: u8 [n,h,w] planes, i32 [n,4096,2] joints, or the state records"""
@@ -77,8 +91,9 @@ def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpix
     n, h, w = frames.shape
     dev = frames.device
     L = _lib.load()
-    if ws is None or (ws.n, ws.h, ws.w) != (n, h, w):
+    if ws is None or not ws.fits(n, h, w) or ws.view.device != dev:
         ws = DetectWorkspace(n, h, w, dev)
+    ws.use(n)
     xy = torch.zeros((n, MAXP, 2), dtype=torch.float64, device=dev)
     ids = torch.zeros((n, MAXP, 2), dtype=torch.int32, device=dev)
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)

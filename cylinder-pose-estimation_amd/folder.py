@@ -94,7 +94,7 @@ def run_folder(json_path, folder_path, output_folder=None, target='cylinder', ch
         for c0 in range(0, len(members), chunk):
             part = members[c0:c0 + chunk]
             batch = torch.stack([frames[i] for i in part])
-            if ws is None or ws.n != len(part):
+            if ws is None or not ws.fits(len(part), shape[0], shape[1]):
                 ws = api.DetectWorkspace(len(part), shape[0], shape[1], batch.device)
             det = api.detect_grid_batch(batch, ws, target=target)
             host = batch.cpu().numpy()

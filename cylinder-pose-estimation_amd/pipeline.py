@@ -3,7 +3,7 @@
 
 This is the loop body of exp_gridDetection.m:55-81 (makePyGridPts L/R, then fitSingleCylinder per frame)
 turned into batched kernel launches; frames are processed in chunks so that the detect workspace stays
-bounded (about 75 MB per 1920x1200 image)."""
+bounded (about 340 MB per 1920x1200 image: DESIGN.md section 6)."""
 import torch
 
 from . import api, fit
@@ -44,9 +44,11 @@ class FramePipeline:
         self._streams = None
 
     def _ws(self, n_img, lane=0):
-        if (lane, n_img) not in self.ws:
-            self.ws[(lane, n_img)] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
-        return self.ws[(lane, n_img)]
+        """one workspace per lane, made for the first (largest) chunk it sees; smaller chunks are laid out inside it"""
+        ws = self.ws.get(lane)
+        if ws is None or not ws.fits(n_img, self.h, self.w):
+            ws = self.ws[lane] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
+        return ws.use(n_img)
 
     def run_chunk(self, left, right, lane=0, frame0=0):
         c = left.shape[0]
