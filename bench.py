@@ -294,7 +294,7 @@ def run_rank(args):
         cpe_amd.lib.load()                               # no CPU fallback: fail loudly
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
     if args.chunk <= 0:
-        args.chunk = 160 if H * W <= 1920 * 1200 else 40   # x lanes x 2 images x ~340 MB (1920x1200) of workspace
+        args.chunk = 192 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~300 MB (1920x1200) / ~940 MB (4K) of workspace
     if scaling == 'strong':
         total = args.frames
         lo, hi = D.shard_range(total, rank, world)
@@ -441,7 +441,7 @@ def main():
     ap.add_argument('--scaling', choices=['strong', 'weak'], default=None,
                     help='default: strong for N > 1 (BASELINE.json configs[3]: the 4096-frame batch sharded N x)')
     ap.add_argument('--chunk', type=int, default=0,
-                    help='stereo frames per kernel batch (workspace size); 0 = 160 at 1920x1200, 40 at 3840x2160 (x --lanes in flight)')
+                    help='stereo frames per kernel batch (workspace size); 0 = 192 at 1920x1200, 56 at 3840x2160 (x --lanes in flight)')
     ap.add_argument('--lanes', type=int, default=2,
                     help='chunks in flight, each on its own HIP stream with its own workspace: the narrow tail of one chunk (fragments, '
                          'lines: one workgroup per image) runs beside the wide kernels of the next')

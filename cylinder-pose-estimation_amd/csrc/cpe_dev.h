@@ -7,10 +7,11 @@ namespace cpe {
 // ---------------------------------------------------------------- per-image state kept in the workspace
 constexpr int MAXROOTS = 131072;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
 // components per threshold of the blob sweep (dark away from the border / bright): grows with the frame, one list entry
-// per 8 pixels (CLAHE turns sensor noise into specks: a 1920x1200 frame with +-9 DN of noise has > 131072 per threshold)
+// per 12 pixels (CLAHE turns sensor noise into specks: a 1920x1200 frame with +-9 DN of noise has ~145 000 per threshold; the
+// three lists are 78 MB of the ~300 MB of workspace per 1920x1200 image)
 __host__ __device__ inline int sweep_cap(int h, int w)
 {
-    long long v = (long long)h * w / 8;
+    long long v = (long long)h * w / 12;
     v = v < 32768 ? 32768 : (v > (1 << 20) ? (1 << 20) : v);
     return (int)((v + 255) / 256 * 256);
 }
