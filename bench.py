@@ -293,7 +293,8 @@ def run_rank(args):
         torch.cuda.set_device(dev)
         cpe_amd.lib.load()                               # no CPU fallback: fail loudly
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
-    if args.chunk <= 0:
+    auto_chunk = args.chunk <= 0
+    if auto_chunk:
         args.chunk = 192 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~300 MB (1920x1200) / ~940 MB (4K) of workspace
     if scaling == 'strong':
         total = args.frames
@@ -302,6 +303,10 @@ def run_rank(args):
         total = args.frames * world
         lo, hi = rank * args.frames, (rank + 1) * args.frames
     F = hi - lo
+    if auto_chunk and F > 0:   # equal chunks, their number a multiple of the lanes (no lane idles through a ragged tail)
+        nch = -(-F // args.chunk)
+        nch = -(-nch // args.lanes) * args.lanes
+        args.chunk = -(-F // nch)
     # ---- synthetic inputs, resident in HBM before the timed region
     if args.stub:
         K1 = K2 = T21 = None; radius = 45.0

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(NT) void k_preprocess(const uint8_t *__restrict__ g
                 const int wq = w >> 2;
 #pragma unroll
                 for (int k = 0; k < A_PER; k++) {
-                    const int i = tid + k * NT;
+                    int i = tid + k * NT;
+                    asm volatile("" : "+v"(i));      // recompute the offsets per tile: hoisted out of the tile loop they
+                                                     // cost 8 registers that spill (one scratch write per workgroup)
                     const int ry = i / (AW / 4), q = i - ry * (AW / 4);
                     pre[k] = i < A_DW ? src[(size_t)ry * wq + q] : 0u;
                 }
