@@ -63,3 +63,48 @@ def test_initial_cylinder_matches_lapack_restatement(seed):
         kdir = -kdir                                                       # eig's sign is LAPACK's choice; the line is the same
     assert np.abs(o0 - org).max() < 1e-11 * max(1.0, np.abs(org).max())
     assert np.abs(d0 - kdir).max() < 1e-12, (np.abs(d0 - kdir).max(), cond)   # seen: 7e-16 at cond(A) <= 28
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_nelder_mead_equals_scipy(seed):
+    """The oracle's restatement of fminsearch.m (called at fitCylinderWPts3.m:38 with TolX = TolFun = 1e-5) against scipy's
+    Nelder-Mead -- an independent implementation of the same published algorithm (Lagarias et al. 1998: 5 % initial simplex,
+    rho 1, chi 2, psi 0.5, sigma 0.5, both tolerances required).  Same objective (the oracle's), same start: the two
+    walks are identical step by step, so the minimiser, the value and both counters are EQUAL, not close."""
+    from scipy.optimize import minimize
+    P = _points(100 + seed, noise=0.05)
+    got = oracle.fit_cylinder(P, 45.0)
+    f = lambda x: oracle.cyl_objective(x, P, 45.0)
+    assert f(got['cyl0']) == got['fvals'][0]
+    r = minimize(f, got['cyl0'], method='Nelder-Mead', options=dict(xatol=1e-5, fatol=1e-5, maxiter=100000, maxfev=100000))
+    assert np.array_equal(r.x, got['cyl'])
+    assert r.fun == got['fvals'][1]
+    assert (r.nit, r.nfev) == (got['iters'], got['evals'])
+
+
+def test_triangulation_matches_lapack_svd():
+    """MATLAB's `triangulate` (fitSingleCylinder.m:15) is the homogeneous DLT: per point the right singular vector of the
+    4 x 4 matrix [x P(3,:) - P(1,:); y P(3,:) - P(2,:)] (both cameras) for the smallest singular value, and the mean of
+    the two reprojection distances.  The oracle takes that vector by one-sided Jacobi rotations; here LAPACK's SVD on the
+    same matrix, and the exact 3-D points the pixels were projected from."""
+    rng = np.random.default_rng(3)
+    K1 = np.array([[2400.0, 0, 960], [0, 2400, 600], [0, 0, 1]]); K2 = np.array([[2390.0, 0, 955], [0, 2395, 610], [0, 0, 1]])
+    a = 0.12
+    T21 = np.eye(4); T21[:3, :3] = [[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]]; T21[:3, 3] = [-120.0, 1.5, 8.0]
+    X = np.stack([rng.uniform(-80, 80, 300), rng.uniform(-60, 60, 300), rng.uniform(420, 560, 300)], 1)
+    P1 = K1 @ np.eye(4)[:3]; P2 = K2 @ T21[:3]
+    h = np.c_[X, np.ones(len(X))]
+    p1 = (h @ P1.T); p1 = p1[:, :2] / p1[:, 2:]
+    p2 = (h @ P2.T); p2 = p2[:, :2] / p2[:, 2:]
+    Xo, err = oracle.triangulate(p1, p2, K1, K2, T21)
+    assert np.abs(Xo - X).max() < 1e-8 and err.max() < 1e-9                 # exact pixels: the rendered points come back
+    p1n = p1 + rng.normal(0, 0.3, p1.shape); p2n = p2 + rng.normal(0, 0.3, p2.shape)
+    Xo, err = oracle.triangulate(p1n, p2n, K1, K2, T21)
+    for i in range(len(X)):
+        A = np.stack([p1n[i, 0] * P1[2] - P1[0], p1n[i, 1] * P1[2] - P1[1], p2n[i, 0] * P2[2] - P2[0], p2n[i, 1] * P2[2] - P2[1]])
+        v = np.linalg.svd(A)[2][-1]
+        Xi = v[:3] / v[3]
+        assert np.abs(Xo[i] - Xi).max() < 1e-7, (i, Xo[i], Xi)
+        q1 = P1 @ np.r_[Xi, 1]; q2 = P2 @ np.r_[Xi, 1]
+        e = (np.linalg.norm(p1n[i] - q1[:2] / q1[2]) + np.linalg.norm(p2n[i] - q2[:2] / q2[2])) / 2
+        assert abs(err[i] - e) < 1e-8
