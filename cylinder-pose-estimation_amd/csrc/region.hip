@@ -946,35 +946,61 @@ __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ im
     // Horizontal pairs always; a vertical pair only if the pair one column to the left is not also a member pair
     // (that pair is connected by induction and joins through the two horizontal links); a diagonal pair only if
     // neither of the two pixels completing the 2x2 square is a member.
+    // The lanes of a pre-linked run (consecutive lanes, consecutive pixels, all pointing at the run's first pixel since
+    // k_sw_new's init pass) share their unions: each lane looks up the roots of its own partners, the run takes the
+    // smallest of them, and only the run's first lane links the run to it.  Lane by lane the same unions were one
+    // memory-side atomic per pixel -- the lanes of a wavefront all read "not linked yet" before any of them links.
     auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
     auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
     const int lane = threadIdx.x & 63;
-    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
+    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {   // wave-uniform: the shuffles below need every lane
         const int e = e0 + threadIdx.x;
         const int i = e < nb ? list[e] : -2;
         const bool prel = sw_prelinked(i, w, lane);   // already points at its run's first pixel (k_sw_new, init pass)
-        if (i < 0) continue;
-        const int y = i / w, x = i - y * w;
-        const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
-        auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
-        const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
-        const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
-        const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
-        if (mL && !prel) uf_unite(Pf, i, i - 1);
-        if (old(vR)) uf_unite(Pf, i, i + 1);
-        if (mU && !(mL && mem(vUL))) uf_unite(Pf, i, i - w);
-        if (old(vD) && !(mL && mem(vDL))) uf_unite(Pf, i, i + w);
-        if (!DARK) {
-            const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
-            const bool mR = mem(vR);
-            if (!mU) {
-                if (mem(vUR) && !mR) uf_unite(Pf, i, i - w + 1);
-                if (mem(vUL) && !mL) uf_unite(Pf, i, i - w - 1);
+        int pr[DARK ? 4 : 8], np = 0;
+        if (i >= 0) {
+            const int y = i / w, x = i - y * w;
+            const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
+            auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
+            const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
+            const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
+            const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
+            if (mL && !prel) pr[np++] = i - 1;
+            if (old(vR)) pr[np++] = i + 1;
+            if (mU && !(mL && mem(vUL))) pr[np++] = i - w;
+            if (old(vD) && !(mL && mem(vDL))) pr[np++] = i + w;
+            if (!DARK) {
+                const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
+                const bool mR = mem(vR);
+                if (!mU) {
+                    if (mem(vUR) && !mR) pr[np++] = i - w + 1;
+                    if (mem(vUL) && !mL) pr[np++] = i - w - 1;
+                }
+                if (!mD) {
+                    if (old(vDR) && !mR) pr[np++] = i + w + 1;
+                    if (old(vDL) && !mL) pr[np++] = i + w - 1;
+                }
             }
-            if (!mD) {
-                if (old(vDR) && !mR) uf_unite(Pf, i, i + w + 1);
-                if (old(vDL) && !mL) uf_unite(Pf, i, i + w - 1);
-            }
+        }
+        int mine = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < (DARK ? 4 : 8); k++)
+            if (k < np) { pr[k] = uf_find_c(Pf, pr[k]); mine = min(mine, pr[k]); }
+        // smallest partner root of the run: segmented min over the lanes that share a first lane
+        const unsigned long long starts = __ballot(i >= 0 && !prel);
+        const int hl = i >= 0 ? 63 - __clzll((long long)(starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)))) : -1 - lane;
+        int m = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int om = __shfl_down(m, d, 64), oh = __shfl_down(hl, d, 64);
+            if (lane + d < 64 && oh == hl) m = min(m, om);
+        }
+        const int runmin = __shfl(m, hl < 0 ? lane : hl, 64);
+        if (i >= 0 && runmin != INT_MAX) {
+            if (lane == hl) uf_unite(Pf, i, runmin);
+#pragma unroll
+            for (int k = 0; k < (DARK ? 4 : 8); k++)
+                if (k < np && pr[k] != runmin) uf_unite(Pf, pr[k], runmin);   // the run joins several components: rare
         }
     }
 }
