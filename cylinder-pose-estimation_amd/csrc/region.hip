@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ im
         int mine = INT_MAX;
 #pragma unroll
         for (int k = 0; k < (DARK ? 4 : 8); k++)
-            if (k < np) { pr[k] = uf_find_c(Pf, pr[k]); mine = min(mine, pr[k]); }
+            if (k < np) { pr[k] = uf_find(Pf, pr[k]); mine = min(mine, pr[k]); }   // read-only walk: k_sw_new flattens every step, the paths are short, and pointer-jumping stores are fabric writes
         // smallest partner root of the run: segmented min over the lanes that share a first lane
         const unsigned long long starts = __ballot(i >= 0 && !prel);
         const int hl = i >= 0 ? 63 - __clzll((long long)(starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)))) : -1 - lane;
@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
         int i = -1, root = -1;
         if (isnew) {
             i = list[e];
-            root = uf_find_c(Pf, i);
+            root = uf_find(Pf, i);
             if (root != i) {
                 Pf[i] = root;
                 if (!DARK) { hpar[f * N + i] = root; htime[f * N + i] = (uint8_t)epoch; }   // joined `root` at this step
