@@ -121,6 +121,79 @@ __global__ __launch_bounds__(256) void k_remap_bilinear1(const uint8_t *__restri
     dst[f * (size_t)N + i] = (uint8_t)remap_one(src + f * (size_t)N, h, w, map_xy[2 * (size_t)i], map_xy[2 * (size_t)i + 1], map_f[i]);
 }
 
+// ---- second mode of row f-3: undistortImage(I, cameraParams, 'cubic') of the MATLAB entry point (utils/preProcessing.m:3-4)
+// [ext] restated as in oracle/src/orc_undistort.c (parity unpinned vs MATLAB): f64 distortPoints per output pixel into a
+// float32 (x, y) map, then cubic convolution (Keys, a = -1/2) in single precision, fill value outside the image.
+struct MatlabCam { double fx, skew, cx, fy, cy, k1, k2, k3, p1, p2; };
+
+__global__ __launch_bounds__(256) void k_undistort_map_matlab(MatlabCam c, int h, int w, float2 *__restrict__ map)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= h * w) return;
+    const int i = p / w, j = p - i * w;
+    const double u = j + 1, v = i + 1;
+    const double y = (v - c.cy) / c.fy, x = ((u - c.cx) - c.skew * y) / c.fx;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r2 * r4;
+    const double alpha = (c.k1 * r2 + c.k2 * r4) + c.k3 * r6;
+    const double xy = x * y;
+    const double dx = 2 * c.p1 * xy + c.p2 * (r2 + 2 * (x * x));
+    const double dy = c.p1 * (r2 + 2 * (y * y)) + 2 * c.p2 * xy;
+    const double xd = (x + x * alpha) + dx, yd = (y + y * alpha) + dy;
+    const double ud = (xd * c.fx + c.cx) + c.skew * yd, vd = yd * c.fy + c.cy;
+    map[p] = make_float2((float)(ud - 1.0), (float)(vd - 1.0));
+}
+
+__device__ __forceinline__ void keys_weights(float t, float *wt)
+{
+    const float t2 = t * t, t3 = t2 * t;
+    wt[0] = ((-t3 + 2.0f * t2) - t) * 0.5f;
+    wt[1] = ((3.0f * t3 - 5.0f * t2) + 2.0f) * 0.5f;
+    wt[2] = ((-3.0f * t3 + 4.0f * t2) + t) * 0.5f;
+    wt[3] = (t3 - t2) * 0.5f;
+}
+
+// one thread per output pixel; the map entry and the 8 weights are made once and applied to REMAP_FRAMES frames.
+// The 16 taps are unconditional loads from clamped addresses (independent, one latency); a tap one step outside the image
+// is replaced by Keys' extrapolation of the other three.
+__global__ __launch_bounds__(256) void k_remap_cubic(const uint8_t *__restrict__ src, int n, int h, int w,
+                                                     const float2 *__restrict__ map, int fill, uint8_t *__restrict__ dst)
+{
+    const int N = h * w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const float2 m = map[p];
+    const float x = m.x, y = m.y;
+    const bool inside = x >= 0.0f && y >= 0.0f && x <= (float)(w - 1) && y <= (float)(h - 1);
+    int ix = (int)floorf(x), iy = (int)floorf(y);
+    ix = min(max(ix, 0), w - 2); iy = min(max(iy, 0), h - 2);
+    float wx[4], wy[4];
+    keys_weights(x - (float)ix, wx);
+    keys_weights(y - (float)iy, wy);
+    const int f0 = blockIdx.y * REMAP_FRAMES, f1 = min(f0 + REMAP_FRAMES, n);
+    for (int f = f0; f < f1; f++) {
+        int out = fill;
+        if (inside) {
+            const uint8_t *s0 = src + f * (size_t)N;
+            float row[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int yy = min(max(iy - 1 + r, 0), h - 1);
+                float s[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) s[c] = (float)s0[(size_t)yy * w + min(max(ix - 1 + c, 0), w - 1)];
+                if (ix - 1 < 0) s[0] = (3.0f * s[1] - 3.0f * s[2]) + s[3];
+                if (ix + 2 >= w) s[3] = (3.0f * s[2] - 3.0f * s[1]) + s[0];
+                row[r] = ((s[0] * wx[0] + s[1] * wx[1]) + s[2] * wx[2]) + s[3] * wx[3];
+            }
+            if (iy - 1 < 0) row[0] = (3.0f * row[1] - 3.0f * row[2]) + row[3];
+            if (iy + 2 >= h) row[3] = (3.0f * row[2] - 3.0f * row[1]) + row[0];
+            const float v = ((row[0] * wy[0] + row[1] * wy[1]) + row[2] * wy[2]) + row[3] * wy[3];
+            out = v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (int)floorf(v + 0.5f));
+        }
+        dst[f * (size_t)N + p] = (uint8_t)out;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t cpe_undistort_map(const double *K, const double *dist, int32_t n_dist, int32_t h, int32_t w,
@@ -165,5 +238,38 @@ extern "C" int32_t cpe_remap_bilinear_batch(const uint8_t *src, int32_t n, int32
         CPE_KLAUNCH(k_remap_bilinear1, dim3((unsigned)((N + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, src, h, w, map_xy, map_f,
                     dst);
     CPE_CHECK_LAUNCH("k_remap_bilinear");
+    return CPE_OK;
+}
+
+extern "C" int32_t cpe_undistort_map_matlab(const double *K, const double *radial, int32_t n_radial, const double *tangential,
+                                            int32_t h, int32_t w, float *map, void *stream)
+{
+    CPE_CHECK_ARG(K && map && (radial || n_radial == 0), "cpe_undistort_map_matlab: null pointer");
+    CPE_CHECK_ARG(n_radial >= 0 && n_radial <= 3, "cpe_undistort_map_matlab: %d radial coefficients (MATLAB takes 2 or 3)", n_radial);
+    CPE_CHECK_ARG(h >= 3 && w >= 3 && (long long)h * w < (1ll << 31), "cpe_undistort_map_matlab: bad size %dx%d", w, h);
+    CPE_CHECK_ARG(K[0] != 0.0 && K[4] != 0.0, "cpe_undistort_map_matlab: zero focal length");
+    MatlabCam c;
+    c.fx = K[0]; c.skew = K[1]; c.cx = K[2]; c.fy = K[4]; c.cy = K[5];
+    c.k1 = n_radial > 0 ? radial[0] : 0.0; c.k2 = n_radial > 1 ? radial[1] : 0.0; c.k3 = n_radial > 2 ? radial[2] : 0.0;
+    c.p1 = tangential ? tangential[0] : 0.0; c.p2 = tangential ? tangential[1] : 0.0;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_undistort_map_matlab, dim3((unsigned)(((size_t)h * w + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c, h, w,
+                reinterpret_cast<float2 *>(map));
+    CPE_CHECK_LAUNCH("k_undistort_map_matlab");
+    return CPE_OK;
+}
+
+extern "C" int32_t cpe_remap_cubic_batch(const uint8_t *src, int32_t n, int32_t h, int32_t w, const float *map, int32_t fill,
+                                         uint8_t *dst, void *stream)
+{
+    CPE_CHECK_ARG(src && dst && map, "cpe_remap_cubic_batch: null pointer");
+    CPE_CHECK_ARG(src != dst, "cpe_remap_cubic_batch: in-place remap is not possible");
+    CPE_CHECK_ARG(n >= 0 && h >= 3 && w >= 3 && (long long)h * w < (1ll << 31), "cpe_remap_cubic_batch: bad size");
+    CPE_CHECK_ARG(fill >= 0 && fill <= 255 && (((size_t)map) & 7) == 0, "cpe_remap_cubic_batch: fill value / map alignment");
+    if (n == 0) return CPE_OK;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_remap_cubic, dim3((unsigned)(((size_t)h * w + 255) / 256), (n + REMAP_FRAMES - 1) / REMAP_FRAMES), dim3(256), 0,
+                (hipStream_t)stream, src, n, h, w, reinterpret_cast<const float2 *>(map), fill, dst);
+    CPE_CHECK_LAUNCH("k_remap_cubic");
     return CPE_OK;
 }

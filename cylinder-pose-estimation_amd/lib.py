@@ -51,6 +51,8 @@ _SIGS = {
                                       [C.c_void_p] * 9),
     'cpe_undistort_map': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cpe_remap_bilinear_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'cpe_undistort_map_matlab': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'cpe_remap_cubic_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_fit_cylinder_batch': (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p] +
                                [C.c_void_p] * 7),
 }

@@ -274,6 +274,18 @@ CPE_API int32_t cpe_undistort_map(const double *K, const double *dist, int32_t n
 CPE_API int32_t cpe_remap_bilinear_batch(const uint8_t *src, int32_t n, int32_t h, int32_t w, const int16_t *map_xy,
                                          const uint16_t *map_f, uint8_t *dst, void *stream);
 
+/* Row f-3, second mode: the MATLAB entry point undistorts with undistortImage(I, cameraParams, 'cubic')
+ * (utils/preProcessing.m:3-4, :15).  Output view 'same', fill value `fill`.
+ *   cpe_undistort_map_matlab: K f64[9] row-major as the camera JSON holds it (createCameraDataJSON.m:7: [fx s cx; 0 fy cy;
+ *     0 0 1] with MATLAB's 1-based principal point), radial f64[n_radial] (n_radial 0..3: k1 k2 [k3]), tangential f64[2] or
+ *     NULL -- HOST pointers; map f32[h,w,2] device buffer: 0-based source (x, y) of every output pixel (distortPoints in f64).
+ *   cpe_remap_cubic_batch: dst[n,h,w] = interp2d(src[n,h,w], map, 'cubic', fill): cubic convolution (a = -1/2) in single
+ *     precision, result rounded half away from zero and saturated; src != dst; h, w >= 3. */
+CPE_API int32_t cpe_undistort_map_matlab(const double *K, const double *radial, int32_t n_radial, const double *tangential,
+                                         int32_t h, int32_t w, float *map, void *stream);
+CPE_API int32_t cpe_remap_cubic_batch(const uint8_t *src, int32_t n, int32_t h, int32_t w, const float *map, int32_t fill,
+                                      uint8_t *dst, void *stream);
+
 /* Row f-1: the per-frame terms of the multi-frame objective of fitCylinderWPts3sAngs.m:82-94 (`dist`):
  * terms[i] = mean((getDistPts3ToLine(Pts3s{i}, line(T * TAGVcyls{i})) - radius)^2), one wavefront per frame.
  * X f64[n,CPE_MAXP,3], cnt i32[n], TAGVcyl f64[n,16] (row-major getTAGVcyl(pan,tilt)), T f64[16] (device, row-major

@@ -245,3 +245,28 @@ def remap_bilinear(src, map_xy, map_f):
 def undistort(src, K, dist):
     mxy, mf = undistort_map(K, dist, src.shape[0], src.shape[1])
     return remap_bilinear(src, mxy, mf)
+
+
+def undistort_map_matlab(K, radial, tangential, h, w):
+    """distortPoints of every output pixel (undistortImage, OutputView 'same') -> float32 [h,w,2] 0-based source (x, y)"""
+    L = lib()
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
+    r = np.ascontiguousarray(np.asarray(radial, dtype=np.float64).ravel()); t = np.ascontiguousarray(np.asarray(tangential, dtype=np.float64).ravel())
+    m = np.empty((h, w, 2), dtype=np.float32)
+    L.orc_undistort_map_matlab(K.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.c_int(r.size),
+                               t.ctypes.data_as(C.c_void_p) if t.size else None, C.c_int(h), C.c_int(w), m.ctypes.data_as(C.c_void_p))
+    return m
+
+
+def remap_cubic(src, map_xy, fill=0):
+    """interp2d(src, X, Y, 'cubic', fill) on a uint8 image"""
+    L = lib()
+    src = np.ascontiguousarray(src, dtype=np.uint8); h, w = src.shape
+    m = np.ascontiguousarray(map_xy, dtype=np.float32); dst = np.empty_like(src)
+    L.orc_remap_cubic(src.ctypes.data_as(C.c_void_p), C.c_int(h), C.c_int(w), m.ctypes.data_as(C.c_void_p), C.c_int(fill),
+                      dst.ctypes.data_as(C.c_void_p))
+    return dst
+
+
+def undistort_matlab(src, K, radial, tangential):
+    return remap_cubic(src, undistort_map_matlab(K, radial, tangential, src.shape[0], src.shape[1]))

@@ -124,3 +124,80 @@ ORC_API int orc_undistort(const uint8_t *src, int h, int w, const double *K, con
     free(mxy); free(mf);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Second mode of row f-3: the MATLAB entry point undistorts with
+ *     undistortImage(I, cameraParams, 'cubic')            utils/preProcessing.m:3-4 (and :15)
+ * [ext] Computer Vision Toolbox code that is not in this image: PARITY UNPINNED.  Restated from the documented model:
+ *   - output view 'same', fill value 0: output pixel (u, v) (MATLAB pixel coordinates, 1-based) looks up the source at
+ *     distortPoints([u v]):  y = (v - cy) / fy;  x = (u - cx - skew * y) / fx;  r2 = x^2 + y^2;
+ *     alpha = k1 r2 + k2 r2^2 + k3 r2^3;  dx = 2 p1 x y + p2 (r2 + 2 x^2);  dy = p1 (r2 + 2 y^2) + 2 p2 x y;
+ *     xd = x + x alpha + dx;  yd = y + y alpha + dy;  ud = xd fx + cx + skew yd;  vd = yd fy + cy        (f64)
+ *   - interp2d(I, X, Y, 'cubic', 0) on a uint8 image works in single precision: cubic convolution (Keys, a = -1/2),
+ *     separable, the sample one step outside the image extrapolated as 3 f0 - 3 f1 + f2 (Keys' boundary condition, what
+ *     interp2 'cubic' pads with), points outside [1, W] x [1, H] take the fill value, the result is cast back to uint8
+ *     (round half away from zero, saturate).
+ * K is the 3x3 matrix of the camera JSON (createCameraDataJSON.m:7: IntrinsicMatrix' = [fx s cx; 0 fy cy; 0 0 1], MATLAB's
+ * 1-based principal point).  The map holds 0-based source coordinates as float32 (x, y). */
+ORC_API void orc_undistort_map_matlab(const double *K, const double *radial, int nr, const double *tang, int h, int w, float *map)
+{
+    const double fx = K[0], skew = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const double k1 = nr > 0 ? radial[0] : 0, k2 = nr > 1 ? radial[1] : 0, k3 = nr > 2 ? radial[2] : 0;
+    const double p1 = tang ? tang[0] : 0, p2 = tang ? tang[1] : 0;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const double u = j + 1, v = i + 1;
+            const double y = (v - cy) / fy, x = ((u - cx) - skew * y) / fx;
+            const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r2 * r4;
+            const double alpha = (k1 * r2 + k2 * r4) + k3 * r6;
+            const double xy = x * y;
+            const double dx = 2 * p1 * xy + p2 * (r2 + 2 * (x * x));
+            const double dy = p1 * (r2 + 2 * (y * y)) + 2 * p2 * xy;
+            const double xd = (x + x * alpha) + dx, yd = (y + y * alpha) + dy;
+            const double ud = (xd * fx + cx) + skew * yd, vd = yd * fy + cy;
+            map[((size_t)i * w + j) * 2] = (float)(ud - 1.0);
+            map[((size_t)i * w + j) * 2 + 1] = (float)(vd - 1.0);
+        }
+}
+
+static void orc_keys_weights(float t, float *wt)
+{
+    const float t2 = t * t, t3 = t2 * t;
+    wt[0] = ((-t3 + 2.0f * t2) - t) * 0.5f;
+    wt[1] = ((3.0f * t3 - 5.0f * t2) + 2.0f) * 0.5f;
+    wt[2] = ((-3.0f * t3 + 4.0f * t2) + t) * 0.5f;
+    wt[3] = (t3 - t2) * 0.5f;
+}
+
+ORC_API void orc_remap_cubic(const uint8_t *src, int h, int w, const float *map, int fill, uint8_t *dst)
+{
+    for (size_t p = 0; p < (size_t)h * w; p++) {
+        const float x = map[2 * p], y = map[2 * p + 1];
+        int out = fill;
+        if (h >= 3 && w >= 3 && x >= 0.0f && y >= 0.0f && x <= (float)(w - 1) && y <= (float)(h - 1)) {
+            int ix = (int)floorf(x), iy = (int)floorf(y);
+            if (ix > w - 2) ix = w - 2;
+            if (iy > h - 2) iy = h - 2;
+            float wx[4], wy[4], row[4];
+            orc_keys_weights(x - (float)ix, wx);
+            orc_keys_weights(y - (float)iy, wy);
+            for (int r = 0; r < 4; r++) {
+                const int yy = iy - 1 + r;
+                if (yy < 0 || yy >= h) { row[r] = 0; continue; }
+                float s[4];
+                for (int c = 0; c < 4; c++) {
+                    const int xx = ix - 1 + c;
+                    s[c] = (xx >= 0 && xx < w) ? (float)src[(size_t)yy * w + xx] : 0.0f;
+                }
+                if (ix - 1 < 0) s[0] = (3.0f * s[1] - 3.0f * s[2]) + s[3];
+                if (ix + 2 >= w) s[3] = (3.0f * s[2] - 3.0f * s[1]) + s[0];
+                row[r] = ((s[0] * wx[0] + s[1] * wx[1]) + s[2] * wx[2]) + s[3] * wx[3];
+            }
+            if (iy - 1 < 0) row[0] = (3.0f * row[1] - 3.0f * row[2]) + row[3];
+            if (iy + 2 >= h) row[3] = (3.0f * row[2] - 3.0f * row[1]) + row[0];
+            const float v = ((row[0] * wy[0] + row[1] * wy[1]) + row[2] * wy[2]) + row[3] * wy[3];
+            out = v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (int)floorf(v + 0.5f));
+        }
+        dst[p] = (uint8_t)out;
+    }
+}

@@ -117,3 +117,96 @@ def test_gpu_undistort_feeds_detect(tmp_path):
     d1 = api.detect_grid_batch(out[None])
     assert int(d0['status'][0]) == 0 and int(d1['status'][0]) == 0
     assert abs(int(d0['n'][0]) - int(d1['n'][0])) <= 40
+
+
+# ---------------------------------------------------------------- second mode: undistortImage(I, cameraParams, 'cubic') (preProcessing.m:3-4)
+def _keys(t):
+    return np.stack([(-t**3 + 2 * t**2 - t) / 2, (3 * t**3 - 5 * t**2 + 2) / 2, (-3 * t**3 + 4 * t**2 + t) / 2, (t**3 - t**2) / 2], -1)
+
+
+def _cubic_numpy(src, m, fill=0):
+    """cubic convolution in float64, written independently of the C restatement: pad the image by one Keys-extrapolated
+    sample on every side, then gather 4 x 4 taps"""
+    h, w = src.shape
+    P = np.zeros((h + 2, w + 2)); P[1:-1, 1:-1] = src
+    P[1:-1, 0] = 3 * P[1:-1, 1] - 3 * P[1:-1, 2] + P[1:-1, 3]; P[1:-1, -1] = 3 * P[1:-1, -2] - 3 * P[1:-1, -3] + P[1:-1, -4]
+    P[0] = 3 * P[1] - 3 * P[2] + P[3]; P[-1] = 3 * P[-2] - 3 * P[-3] + P[-4]
+    x = m[..., 0].astype(np.float64); y = m[..., 1].astype(np.float64)
+    inside = (x >= 0) & (y >= 0) & (x <= w - 1) & (y <= h - 1)
+    ix = np.clip(np.floor(x).astype(int), 0, w - 2); iy = np.clip(np.floor(y).astype(int), 0, h - 2)
+    wx = _keys(x - ix); wy = _keys(y - iy)
+    acc = np.zeros(x.shape)
+    for r in range(4):
+        for c in range(4):
+            acc += wy[..., r] * wx[..., c] * P[iy + r, ix + c]          # padded index = image index + 1; taps at -1..2
+    out = np.clip(np.floor(acc + 0.5), 0, 255)
+    return np.where(inside, out, fill).astype(np.uint8), acc, inside
+
+
+def test_oracle_matlab_mode_structure():
+    oracle.build()
+    h, w = 240, 320
+    K = np.array([[700.0, 0.4, 160.7], [0, 702.0, 121.3], [0, 0, 1.0]])     # MATLAB convention: 1-based principal point
+    m = oracle.undistort_map_matlab(K, [0, 0, 0], [0, 0], h, w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    assert np.abs(m[..., 0] - xx).max() < 1e-4 and np.abs(m[..., 1] - yy).max() < 1e-4   # no distortion: identity map
+    src = _frame(h, w, 2)
+    ident = np.stack([xx, yy], -1).astype(np.float32)
+    assert np.array_equal(oracle.remap_cubic(src, ident), src)                # integer positions: weights (0, 1, 0, 0)
+    ramp = np.clip(20 + 0.5 * xx + 0.25 * yy, 0, 255).astype(np.float64)     # cubic convolution reproduces linear functions,
+    sh = ident + np.float32(0.5)                                             # up to the image border (Keys' extrapolation is linear-exact)
+    got = oracle.remap_cubic(ramp.astype(np.uint8), sh)
+    want, acc, inside = _cubic_numpy(ramp.astype(np.uint8), sh)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert (got[~inside] == 0).all() and inside[:-1, :-1].all() and not inside[-1].any() and not inside[:, -1].any()
+    # the distortion model against a plain numpy evaluation
+    rad, tan = [-0.19, 0.06, -0.011], [0.0012, -0.0007]
+    m = oracle.undistort_map_matlab(K, rad, tan, h, w).astype(np.float64)
+    u, v = xx + 1.0, yy + 1.0
+    y = (v - K[1, 2]) / K[1, 1]; x = (u - K[0, 2] - K[0, 1] * y) / K[0, 0]
+    r2 = x * x + y * y
+    a = rad[0] * r2 + rad[1] * r2**2 + rad[2] * r2**3
+    xd = x + x * a + 2 * tan[0] * x * y + tan[1] * (r2 + 2 * x * x); yd = y + y * a + tan[0] * (r2 + 2 * y * y) + 2 * tan[1] * x * y
+    assert np.abs(m[..., 0] - (xd * K[0, 0] + K[0, 2] + K[0, 1] * yd - 1)).max() < 1e-4
+    assert np.abs(m[..., 1] - (yd * K[1, 1] + K[1, 2] - 1)).max() < 1e-4
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_oracle_cubic_matches_float64_restatement(seed):
+    oracle.build()
+    rng = np.random.default_rng(seed)
+    h, w = 97, 131
+    src = _frame(h, w, seed)
+    m = np.stack([rng.uniform(-2, w + 1, (h, w)), rng.uniform(-2, h + 1, (h, w))], -1).astype(np.float32)
+    m[0, :8] = [[0, 0], [w - 1, h - 1], [0.25, 0], [w - 1.25, h - 1], [0, 0.5], [w - 1, h - 1.5], [1e-3, 1e-3], [w - 1 - 1e-3, 5]]
+    got = oracle.remap_cubic(src, m)
+    want, acc, inside = _cubic_numpy(src, m)
+    assert (got[~inside] == 0).all()
+    near_half = np.abs(acc - np.floor(acc) - 0.5) < 1e-3                      # single vs double arithmetic may round these differently
+    assert np.array_equal(got[inside & ~near_half], want[inside & ~near_half])
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert got[0, 0] == src[0, 0] and got[0, 1] == src[h - 1, w - 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w,nr', [(1200, 1920, 2), (483, 650, 3), (64, 67, 3)])
+def test_gpu_matlab_undistort_matches_oracle(h, w, nr):
+    import torch
+    import cpe_amd
+    from cpe_amd import iotool
+    oracle.build()
+    K = K0.copy(); K[0, 2] = w / 2 + 3.3; K[1, 2] = h / 2 - 2.1; K[0, 0] = 0.8 * w; K[1, 1] = 0.81 * w; K[0, 1] = 0.3
+    rad = [-0.23, 0.09, -0.015][:nr]; tan = [0.0013, -0.0008]
+    cam = _cam(rad, tan, K)
+    und = iotool.Undistorter(cam, h, w, 'cuda:0', interp='cubic')
+    m = oracle.undistort_map_matlab(K, rad, tan, h, w)
+    assert np.array_equal(und.map.cpu().numpy(), m)
+    frames = np.stack([_frame(h, w, s) for s in range(10)])                 # more than one REMAP_FRAMES group
+    out = und(torch.from_numpy(frames).cuda()).cpu().numpy()
+    for i in range(len(frames)):
+        assert np.array_equal(out[i], oracle.remap_cubic(frames[i], m))
+    col = np.ascontiguousarray(np.moveaxis(frames[:3], 0, 2))
+    got = iotool.undistort_image(col, cam, interp='cubic')
+    assert got.shape == col.shape and np.array_equal(got[..., 2], out[2])
+    left, right = iotool.preprocessing(frames[0], col, cam, cam)               # preProcessing.m: grey stays, colour -> rgb2gray
+    assert np.array_equal(left, out[0]) and right.shape == (h, w) and right.dtype == np.uint8
