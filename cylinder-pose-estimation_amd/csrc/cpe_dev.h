@@ -6,13 +6,17 @@ namespace cpe {
 
 // ---------------------------------------------------------------- per-image state kept in the workspace
 constexpr int MAXROOTS = 131072;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
-// components per threshold of the blob sweep (dark away from the border / bright): grows with the frame, one list entry
-// per 12 pixels (CLAHE turns sensor noise into specks: a 1920x1200 frame with +-9 DN of noise has ~145 000 per threshold; the
-// three lists are 78 MB of the ~300 MB of workspace per 1920x1200 image)
-__host__ __device__ inline int sweep_cap(int h, int w)
+// component lists of the blob sweep: one pool of (first pixel, count) entries per frame and list, the 17 thresholds one
+// after the other in the order they are filled (the first entry of a threshold = the sum of the counters of the ones before
+// it, region.hip sw_slot).  CLAHE turns sensor noise into specks: 1920x1200 frames with +-7..11 DN of noise were seen with
+// 200 000 dark components away from the border, 560 000 bright ones and 57 000 followed hole borders over all thresholds
+// (tools/overflow_census.py); clean frames stay below 30 000.
+enum { SWL_DARK = 0, SWL_BRIGHT = 1, SWL_TRACE = 2 };
+__host__ __device__ inline int sweep_pool(int h, int w, int which)
 {
-    long long v = (long long)h * w / 12;
-    v = v < 32768 ? 32768 : (v > (1 << 20) ? (1 << 20) : v);
+    const long long N = (long long)h * w;
+    long long v = which == SWL_BRIGHT ? N / 3 : (which == SWL_DARK ? N / 6 : N / 12);
+    v = v < 65536 ? 65536 : (v > (1 << 23) ? (1 << 23) : v);
     return (int)((v + 255) / 256 * 256);
 }
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle

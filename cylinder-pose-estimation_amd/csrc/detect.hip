@@ -84,7 +84,7 @@ Layout make_layout(int n, int h, int w)
     per[P_LAB2] = N * 4;
     per[P_LAB3] = N * 4;
     per[P_SW] = 192 * sizeof(int);
-    per[P_TL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
+    per[P_TL] = (size_t)sweep_pool(h, w, SWL_TRACE) * sizeof(int2);
     per[P_BK] = N * 4;
     per[P_LABP] = N * 4;
     per[P_LABS] = N * 4;
@@ -96,8 +96,8 @@ Layout make_layout(int n, int h, int w)
     per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 3 * sizeof(double);
     per[P_FLJ] = (size_t)2 * h * ((w + 63) / 64) * sizeof(unsigned long long);   // joints chain: background / outer-background bit masks
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);
-    per[P_HL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
-    per[P_BL] = (size_t)17 * sweep_cap(h, w) * sizeof(int2);
+    per[P_HL] = (size_t)sweep_pool(h, w, SWL_DARK) * sizeof(int2);
+    per[P_BL] = (size_t)sweep_pool(h, w, SWL_BRIGHT) * sizeof(int2);
     per[P_SUBPIX] = (size_t)2 * MAXL * 2 * (size_t)(std::max(h, w) + 128) * sizeof(float);
     size_t o = 0;
     for (int i = 0; i < P_COUNT; i++) {

@@ -197,6 +197,18 @@ enum {
 };
 static_assert(SW_NA + NTHR <= SW_STRIDE, "sweep counters");
 
+// a threshold's share of a pooled list (cpe_dev.h sweep_pool): first entry and number of entries that fit.  `desc`: the
+// list is filled from the highest threshold down (bright sweep).  The counters of the thresholds not yet reached are 0.
+struct SwSlot { int off, cnt; };
+__device__ __forceinline__ SwSlot sw_slot(const int *S, int cnt_base, int slot, bool desc, int pool)
+{
+    int o = 0;
+    if (desc) { for (int j = NTHR - 1; j > slot; j--) o += S[cnt_base + j]; }
+    else { for (int j = 0; j < slot; j++) o += S[cnt_base + j]; }
+    o = min(o, pool);
+    return SwSlot{o, min(S[cnt_base + slot], pool - o)};
+}
+
 // one thread per component and threshold: outer border (is_hole = 0) or hole border (is_hole = 1).
 // lists[f][slot][k] = (raster-first pixel, pixel count of the hole | pixels of the holes the bright component encloses)
 // Border points of the hole traces are kept while the border is followed the first time, in 128-byte chunks of a pool
@@ -267,14 +279,14 @@ struct StoreVisitor {
 // one border per lane; a few wavefronts per (frame, threshold) take the list entries in turns (a grid sized for the list
 // capacity would be millions of empty workgroups; see frame_waves)
 template <int is_hole>
-__device__ __forceinline__ void blob_trace_one(int f, int slot, int k, int h, int w, const int2 *__restrict__ lists,
+__device__ __forceinline__ void blob_trace_one(int f, int slot, int k, int h, int w, const int2 *__restrict__ list,
                                                FrameState *__restrict__ st, int *__restrict__ S, BlobRec *__restrict__ blobs_all,
                                                int *__restrict__ blob_d_all, double *__restrict__ dists_all,
                                                const uint32_t *__restrict__ bits, uint32_t *__restrict__ pool_all,
                                                unsigned short *__restrict__ blob_ch_all, int maxch, int maxdf,
                                                unsigned long long *s_win, unsigned short *s_ids)
 {
-    const int2 e = lists[((size_t)f * NTHR + slot) * sweep_cap(h, w) + k];
+    const int2 e = list[k];
     const int root = e.x;
     // exact prunes: a hole's polygon area is >= its pixel count; a bright component's outer polygon contains the
     // unit squares of every pixel of every hole it encloses, so its area is >= their total pixel count
@@ -341,9 +353,12 @@ __global__ __launch_bounds__(64) void k_blob_trace(const uint8_t *__restrict__ c
     __shared__ unsigned short s_ids[CH_DIRECT * 64];
     const int f = blockIdx.y, slot = blockIdx.z;
     int *S = sw + (size_t)f * SW_STRIDE;
-    const int cnt = min(S[cnt_base + slot], sweep_cap(h, w));
+    const int pool = sweep_pool(h, w, is_hole ? SWL_TRACE : SWL_BRIGHT);
+    const SwSlot sl = sw_slot(S, cnt_base, slot, !is_hole, pool);
+    const int cnt = sl.cnt;
+    const int2 *list = lists + (size_t)f * pool + sl.off;
     for (int k = blockIdx.x * 64 + threadIdx.x; k < cnt; k += gridDim.x * 64)
-        blob_trace_one<is_hole>(f, slot, k, h, w, lists, st, S, blobs_all, blob_d_all, dists_all, bits, pool_all, blob_ch_all, maxch, maxdf,
+        blob_trace_one<is_hole>(f, slot, k, h, w, list, st, S, blobs_all, blob_d_all, dists_all, bits, pool_all, blob_ch_all, maxch, maxdf,
                                 s_win, s_ids);
 }
 
@@ -837,19 +852,20 @@ __global__ __launch_bounds__(ENC_NT) void k_enclosed_all(const int2 *__restrict_
     const int *hp = hpar + f * N;
     const uint8_t *ht = htime + f * N;
     int *ef = encl + f * N;
-    const size_t cap = (size_t)sweep_cap(h, w);
+    const int pool_h = sweep_pool(h, w, SWL_DARK), pool_l = sweep_pool(h, w, SWL_BRIGHT);
     for (int slot = 0; slot < NTHR; slot++) {
         const int t = NTHR - 1 - slot;                     // bright step of this threshold
-        const int nh = min(S[SW_NH + slot], cap), nl = min(S[SW_NL + slot], cap);
+        const SwSlot sh = sw_slot(S, SW_NH, slot, false, pool_h), sl = sw_slot(S, SW_NL, slot, true, pool_l);
+        const int nh = sh.cnt, nl = sl.cnt;
         for (int k = threadIdx.x; k < nh; k += ENC_NT) {
-            const int2 e = hl[(f * NTHR + slot) * cap + k];
+            const int2 e = hl[f * pool_h + sh.off + k];
             int c = e.x - 1;                               // bright pixel west of the hole
             while ((int)ht[c] <= t) c = hp[c];
             atomicAdd(&ef[c], min(e.y, 5000));
         }
         __syncthreads();
         for (int k = threadIdx.x; k < nl; k += ENC_NT) {
-            int2 &g = bl[(f * NTHR + slot) * cap + k];
+            int2 &g = bl[f * pool_l + sl.off + k];
             g.y = atomicExch(&ef[g.x], 0);
         }
         __syncthreads();
@@ -1078,6 +1094,8 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
         }
     }
     if (bucket < 1) return;
+    const int pool = sweep_pool(h, w, DARK ? SWL_DARK : SWL_BRIGHT);
+    const int loff = sw_slot(S, cnt_base, slot, !DARK, pool).off;   // the counters of the other thresholds are at rest
     for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
         const int e = e0 + threadIdx.x;
         const bool isnew = e < nb;
@@ -1103,28 +1121,38 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
                 active &= ~same;
             }
         } else if (is_root) acc[f * N + i] = 0;
-        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * (size_t)sweep_cap(h, w), &st[f], sweep_cap(h, w));
+        sw_append(is_root, i, &sw[f * SW_STRIDE + cnt_base + slot], lists + f * (size_t)pool + loff, &st[f], pool - loff);
     }
 }
 
 // components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
 // Merged into another (DARK): hand its pixel count to the component that absorbed it.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_elem_stride, int src_cap,
-                                                const int *__restrict__ src_cnt, int src_cnt_stride,
+__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_cap,
+                                                const int *__restrict__ src_cnt, int src_cnt_stride, int src_slot,
                                                 int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
                                                 int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
                                                 int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
                                                 int *__restrict__ hpar, uint8_t *__restrict__ htime)
 {
+    // source: the list of threshold `src_slot` (the previous step) or, for the first dark step (src_slot < 0), the root list
+    // of the run-based labelling (src: ints, src_frame_stride apart, src_cnt[f * src_cnt_stride] of them)
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const int ns = min(src_cnt[f * src_cnt_stride], src_cap);
+    const int *S = sw + f * SW_STRIDE;
+    const int pool = sweep_pool(h, w, DARK ? SWL_DARK : SWL_BRIGHT);
+    const int loff = sw_slot(S, cnt_base, slot, !DARK, pool).off;
+    int ns, es = 1;
+    const int *sp;
+    if (src_slot >= 0) {
+        const SwSlot ss = sw_slot(S, cnt_base, src_slot, !DARK, pool);
+        ns = ss.cnt; es = 2; sp = reinterpret_cast<const int *>(lists + f * (size_t)pool + ss.off);
+    } else { ns = min(src_cnt[f * src_cnt_stride], src_cap); sp = src + f * src_frame_stride; }
     for (int k0 = blockIdx.x * 256; k0 < ns; k0 += gridDim.x * 256) {   // wave-uniform: sw_append is a wavefront collective
     const int k = k0 + threadIdx.x;
     bool keep = false;
     int r = 0;
     if (k < ns) {
-        r = src[f * src_frame_stride + (size_t)k * src_elem_stride];
+        r = sp[(size_t)k * es];
         int *Pf = P + f * N;
         if (DARK) {
             if (touch[f * N + r] != (uint8_t)epoch) {
@@ -1137,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
             else { hpar[f * N + r] = uf_find_c(Pf, r); htime[f * N + r] = (uint8_t)epoch; }   // absorbed at this step
         }
     }
-    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + (f * NTHR + slot) * (size_t)sweep_cap(h, w), &st[f], sweep_cap(h, w));
+    sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + f * (size_t)pool + loff, &st[f], pool - loff);
     }
 }
 
@@ -1150,15 +1178,18 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
                                                  int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
 {
     const size_t N = (size_t)h * w, f = blockIdx.y;
-    const size_t cap = (size_t)sweep_cap(h, w);
-    const int cnt = min(sw[f * SW_STRIDE + cnt_base + slot], (int)cap);
+    const int *S = sw + f * SW_STRIDE;
+    const int pool = sweep_pool(h, w, SWL_DARK), pool_t = sweep_pool(h, w, SWL_TRACE);
+    const SwSlot sl = sw_slot(S, cnt_base, slot, false, pool);
+    const int cnt = sl.cnt;
+    const int toff = trace ? sw_slot(S, SW_NT, slot, false, pool_t).off : 0;
     const int lane = threadIdx.x & 63;
     for (int k0 = blockIdx.x * 256; k0 < cnt; k0 += gridDim.x * 256) {
         const int k = k0 + threadIdx.x;
         const bool valid = k < cnt;
         int2 e = make_int2(0, 0);
         if (valid) {
-            int2 &g = lists[(f * NTHR + slot) * cap + k];
+            int2 &g = lists[f * (size_t)pool + sl.off + k];
             g.y = acc[f * N + g.x];
             e = g;
         }
@@ -1170,7 +1201,11 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
         int base = 0;
         if (lane == leader) base = atomicAdd(&sw[f * SW_STRIDE + SW_NT + slot], __popcll(b));
         base = __shfl(base, leader, 64);
-        if (want) trace[(f * NTHR + slot) * cap + base + __popcll(b & ((1ull << lane) - 1ull))] = e;   // a subset: always fits
+        if (want) {
+            const int q = toff + base + __popcll(b & ((1ull << lane) - 1ull));
+            if (q < pool_t) trace[f * (size_t)pool_t + q] = e;
+            else set_overflow(st[f], OVF_SWEEP);
+        }
     }
 }
 
@@ -1555,7 +1590,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
-    const int swcap = sweep_cap(h, w);
+    const int swcap = std::max(32768, (int)std::min<long long>(1 << 20, (long long)N / 12));   // grid sizing only: entries one threshold may hold
     const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
@@ -1565,7 +1600,6 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_CHECK_LAUNCH("grey-level buckets");
     }
     const int per = 2 * w + 2 * h;
-    const size_t lstride = (size_t)NTHR * swcap * 2;   // ints per frame of a list array
     // the dark sweep and the hole borders run on the helper stream (if any) beside the bright sweep: the two forests
     // only meet in k_enclosed_all
     hipStream_t ds = side ? side->s : s;
@@ -1581,8 +1615,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
             // first entries of the pixels that join at the next step (bucket 1)
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, 0, 1, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
-            CPE_KLAUNCH(k_sw_old<true>, dim3(frame_waves(n, 8, MAXROOTS / 256), n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, 1, (int)MAXROOTS, (const int *)&st[0].n_roots,
-                        (int)(sizeof(FrameState) / sizeof(int)), h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
+            CPE_KLAUNCH(k_sw_old<true>, dim3(frame_waves(n, 8, MAXROOTS / 256), n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, (int)MAXROOTS, (const int *)&st[0].n_roots,
+                        (int)(sizeof(FrameState) / sizeof(int)), -1, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
         } else {
             CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, ds, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
@@ -1591,8 +1625,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, k + 1 < NTHR ? k + 1 : 0, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)B.hl + (size_t)(k - 1) * swcap * 2, lstride, 2, swcap,
-                        (const int *)(B.sw + SW_NH + k - 1), (int)SW_STRIDE, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
+            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)nullptr, (size_t)0, 0,
+                        (const int *)nullptr, 0, k - 1, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
                         B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
         }
         CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, ds, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
@@ -1621,8 +1655,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
                     (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
         if (j > 0)
-            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)B.bl + (size_t)(k + 1) * swcap * 2, lstride, 2, swcap,
-                        (const int *)(B.sw + SW_NL + k + 1), (int)SW_STRIDE, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, j,
+            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)nullptr, (size_t)0, 0,
+                        (const int *)nullptr, 0, k + 1, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, j,
                         B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }

@@ -39,8 +39,8 @@ def run(frames, tag, chunk=16):
             d = st[i]
             line = (f'{tag} frame {i0 + i}: status {s} ovf {bits(d["overflow"])} pts {int(det["n"][i])} rows {d["n_rows"]} cols {d["n_cols"]} '
                     f'joints {d["n_joints"]}/{d["n_joints_all"]} groups {d["n_groups"]} kp {d["n_kp"]} roots {d["n_roots"]}/{d["n_roots_p"]}/{d["n_roots_s"]} '
-                    f'seg {d["n_seg0"]},{d["n_seg1"]} dark max {sw[i, 8:25].max()} bright max {sw[i, 25:42].max()} blobs max {sw[i, 42:59].max()}')
-            if s == 6 or (i0 + i) < 2:
+                    f'seg {d["n_seg0"]},{d["n_seg1"]} dark max {sw[i, 8:25].max()} sum {sw[i, 8:25].sum()} bright max {sw[i, 25:42].max()} sum {sw[i, 25:42].sum()} trace sum {sw[i, 130:147].sum()} blobs max {sw[i, 42:59].max()}')
+            if s == 6 or (i0 + i) < 2 or os.environ.get('CENSUS_ALL'):
                 print(line)
             if s == 6 and save_dir and saved[0] < 3:
                 os.makedirs(save_dir, exist_ok=True)
