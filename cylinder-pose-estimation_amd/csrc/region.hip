@@ -612,7 +612,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     __shared__ double cX[64], cY[64], cR[64];   // middle centre each blob's group gets if the blob is inserted
     __shared__ int cG[64], s_bad[64];
     __shared__ int pn[64], pg[64], pd[64], s_jm[64], s_mod[64];
-    __shared__ int s_ng, s_serial, s_adv;
+    __shared__ int s_ng, s_serial, s_adv, s_maxn;
     const int f = blockIdx.x, t = threadIdx.x, lane = t & 63;
     FrameState &S = st[f];
     int *ord = order + (size_t)f * MAXB;
@@ -634,10 +634,17 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     for (int thr = 0; thr < NTHR; thr++) {
         const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + thr], MAXB);
         const BlobRec *B = blobs_all + ((size_t)f * NTHR + thr) * MAXB;
-        for (int i = t; i < nb; i += MG_NT) {
-            int ki = B[i].key, rank = 0;
-            for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0;
-            ord[rank] = i;
+        {   // rank by key (keys are distinct); the keys are staged in the list buffer, which is idle between thresholds
+            int *keys = reinterpret_cast<int *>(&pl[0][0]);
+            static_assert(sizeof(pl) >= sizeof(int) * MAXB, "key staging");
+            for (int i = t; i < nb; i += MG_NT) keys[i] = B[i].key;
+            __syncthreads();
+            for (int i = t; i < nb; i += MG_NT) {
+                const int ki = keys[i];
+                int rank = 0;
+                for (int j = 0; j < nb; j++) rank += (keys[j] > ki) ? 1 : 0;
+                ord[rank] = i;
+            }
         }
         __syncthreads();
         const int ng0 = ng;   // centres of this threshold are only compared with groups of the earlier ones
@@ -655,9 +662,13 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 const bool act = lane < qn;
                 const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
                 int first = act ? INT_MAX : -1;
-                for (int j = jlo; j < jhi; j++) {
-                    if (first == INT_MAX && mid_joins(j, cx, cy, cr)) first = j;
-                    if ((j & 15) == 15 && !__ballot(first == INT_MAX)) break;
+                for (int j = jlo; j < jhi; j += 4) {   // four groups per round: their centres are read together
+                    int hit = INT_MAX;
+#pragma unroll
+                    for (int u = 3; u >= 0; u--)
+                        if (j + u < jhi && mid_joins(j + u, cx, cy, cr)) hit = j + u;
+                    first = min(first, hit);
+                    if (!__ballot(first == INT_MAX)) break;
                 }
                 if (act && first != INT_MAX) atomicMin(&s_jm[lane], first);
             }
@@ -673,13 +684,32 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 if (first) pg[t] = g;
             }
             __syncthreads();
-            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += MG_NT) {
-                const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
-                const int g = pg[q];
-                if (g >= 0) {
-                    const int gn = G[g].n;             // only the entries in use are fetched
-                    if (e == GCAP * 3) pn[q] = gn;
-                    else if (e < 3 * gn) pl[e][q] = G[g].c[e / 3][e % 3];
+            // list lengths first (one round trip), then only the entries in use, every thread's loads in flight together
+            if (t < 64) {
+                const int g = pg[t];
+                const int gn = g >= 0 ? G[g].n : 0;
+                pn[t] = gn;
+                int mx = gn;
+                for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+                if (t == 0) s_maxn = mx;
+            }
+            __syncthreads();
+            {
+                const int per = 3 * s_maxn;                      // doubles per slot to look at (<= GCAP * 3)
+                for (int idx0 = 0; idx0 < 64 * per; idx0 += 4 * MG_NT) {
+                    double v[4];
+                    int qq[4], ee[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int idx = idx0 + u * MG_NT + t;
+                        const int q = idx / per, e = idx - q * per;
+                        const bool on = idx < 64 * per && pg[q] >= 0 && e < 3 * pn[q];
+                        qq[u] = on ? q : -1; ee[u] = e;
+                        v[u] = on ? G[pg[q]].c[e / 3][e % 3] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (qq[u] >= 0) pl[ee[u]][qq[u]] = v[u];
                 }
             }
             __syncthreads();
