@@ -847,15 +847,23 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 }
                 if (t == 0) s_ng = ng;
             }
+            if (t < 64) {   // longest changed list (same wavefront as the two insertion paths above)
+                int mx = (pg[lane] >= 0 && pd[lane]) ? pn[lane] : 0;
+                for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+                if (t == 0) s_maxn = mx;
+            }
             __syncthreads();
             ng = s_ng;
             // 4. changed lists back to HBM
-            for (int idx = t; idx < 64 * (GCAP * 3 + 1); idx += MG_NT) {
-                const int q = idx / (GCAP * 3 + 1), e = idx - q * (GCAP * 3 + 1);
-                const int g = pg[q];
-                if (g >= 0 && pd[q]) {
-                    if (e == GCAP * 3) G[g].n = pn[q];
-                    else if (e < pn[q] * 3) G[g].c[e / 3][e % 3] = pl[e][q];
+            {
+                const int per = 3 * s_maxn + 1;                  // + 1: the length
+                for (int idx = t; idx < 64 * per && per > 1; idx += MG_NT) {
+                    const int q = idx / per, e = idx - q * per;
+                    const int g = pg[q];
+                    if (g >= 0 && pd[q]) {
+                        if (e == per - 1) G[g].n = pn[q];
+                        else if (e < pn[q] * 3) G[g].c[e / 3][e % 3] = pl[e][q];
+                    }
                 }
             }
             q0 += s_adv;
