@@ -15,8 +15,9 @@ enum { SWL_DARK = 0, SWL_BRIGHT = 1, SWL_TRACE = 2 };
 __host__ __device__ inline int sweep_pool(int h, int w, int which)
 {
     const long long N = (long long)h * w;
-    long long v = which == SWL_BRIGHT ? N / 3 : (which == SWL_DARK ? N / 6 : N / 12);
-    v = v < 65536 ? 65536 : (v > (1 << 23) ? (1 << 23) : v);
+    long long v = which == SWL_BRIGHT ? N / 2 : (which == SWL_DARK ? N / 4 : N / 8);   // twice the largest sums seen
+    const long long lo = which == SWL_TRACE ? (1 << 18) : (1 << 19);   // small frames: what 17 lists of 32768 entries held
+    v = v < lo ? lo : (v > (1 << 23) ? (1 << 23) : v);
     return (int)((v + 255) / 256 * 256);
 }
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle

@@ -1,6 +1,8 @@
 """Image half on the GPU (through cpe_detect_grid_batch) vs the oracle, stage by stage and end to end.
 Integer / byte stages: bit-exact.  Point coordinates: the kernels run the oracle's f64 operation order,
 so they are compared for equality as well (stated tolerance 0; BASELINE allows 1e-3 px)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -294,3 +296,24 @@ def test_no_capacity_overflow_on_clean_4k_frames(cpe, gpu):
             assert st == [0] * 8, (i0, st, [s['overflow'] for s in ws.state()])
             worst = max(worst, int(det['n'].max()))
     assert 600 < worst <= cpe.fit.MAXP
+
+
+@pytest.mark.gpu
+def test_noisy_small_frames_fit_the_pooled_sweep_lists(cpe, gpu):
+    """The sweep's component lists are pools over the 17 thresholds (cpe_dev.h sweep_pool).  Small frames with heavy sensor
+    noise are the densest case per pixel: the seeds of tools/stress_parity.py that overflowed a first, tighter sizing."""
+    import importlib.util
+    import torch
+    from cpe_amd import api, synth
+    spec = importlib.util.spec_from_file_location('stress_parity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'stress_parity.py'))
+    sp = importlib.util.module_from_spec(spec); spec.loader.exec_module(sp)
+    OVF_SWEEP = 1 << 11
+    for seed in (1012, 1019, 1038, 1052, 1062, 1064, 1071):
+        rng = np.random.default_rng(seed)
+        h, w = sp.SIZES[seed % len(sp.SIZES)]
+        b = synth.render_batch(1, h, w, seed=seed, with_gt=False)
+        frames = np.stack([sp.degrade(img, rng)[0] for img in (b['left'][0].numpy(), b['right'][0].numpy())])
+        det = api.detect_grid_batch(torch.from_numpy(frames).to('cuda:0'))
+        torch.cuda.synchronize()
+        for i, d in enumerate(det['ws'].state()):
+            assert not (d['overflow'] & OVF_SWEEP), (seed, i, d['overflow'])
