@@ -1064,21 +1064,22 @@ __global__ __launch_bounds__(256) void k_sw_touch(const uint8_t *__restrict__ im
                                                   const FrameState *__restrict__ st, const int *__restrict__ P,
                                                   uint8_t *__restrict__ touch, int epoch)
 {
-    const int per = 2 * w + 2 * h;
-    int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= n * per) return;
-    int f = gi / per, k = gi - f * per;
+    // grid (a few workgroups, n): the border pixels of a frame's rectangle in turns (one thread per pixel of the largest
+    // possible border was n * 24 workgroups per launch, nearly all of them empty)
+    const int f = blockIdx.y;
     const SwRect r = sw_rect(st, f);
     if (r.x1 < r.x0) return;
     const int rw = r.x1 - r.x0 + 1, rh = r.y1 - r.y0 + 1;
-    int x, y;
-    if (k < w) { if (k >= rw) return; x = r.x0 + k; y = r.y0; }
-    else if (k < 2 * w) { if (k - w >= rw) return; x = r.x0 + k - w; y = r.y1; }
-    else if (k < 2 * w + h) { if (k - 2 * w >= rh) return; x = r.x0; y = r.y0 + k - 2 * w; }
-    else { if (k - 2 * w - h >= rh) return; x = r.x1; y = r.y0 + k - 2 * w - h; }
     const size_t N = (size_t)h * w;
-    const int p = y * w + x;
-    if ((int)img[f * N + p] <= hi) touch[f * N + uf_find(P + f * N, p)] = (uint8_t)epoch;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < 2 * rw + 2 * rh; k += gridDim.x * blockDim.x) {
+        int x, y;
+        if (k < rw) { x = r.x0 + k; y = r.y0; }
+        else if (k < 2 * rw) { x = r.x0 + k - rw; y = r.y1; }
+        else if (k < 2 * rw + rh) { x = r.x0; y = r.y0 + k - 2 * rw; }
+        else { x = r.x1; y = r.y0 + k - 2 * rw - rh; }
+        const int p = y * w + x;
+        if ((int)img[f * N + p] <= hi) touch[f * N + uf_find(P + f * N, p)] = (uint8_t)epoch;
+    }
 }
 
 __device__ __forceinline__ void sw_append(bool want, int value, int *counter, int2 *list, FrameState *S, int cap)
@@ -1629,7 +1630,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
     const int swcap = std::max(32768, (int)std::min<long long>(1 << 20, (long long)N / 12));   // grid sizing only: entries one threshold may hold
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1637,7 +1638,6 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
         CPE_CHECK_LAUNCH("grey-level buckets");
     }
-    const int per = 2 * w + 2 * h;
     // the dark sweep and the hole borders run on the helper stream (if any) beside the bright sweep: the two forests
     // only meet in k_enclosed_all
     hipStream_t ds = side ? side->s : s;
@@ -1648,7 +1648,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         if (k == 0) {
             // the bulk of the dark set: run-based labelling, flattened; pixels outside it start as singletons
             if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 2)) != CPE_OK) return rc;
-            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
+            CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             // first entries of the pixels that join at the next step (bucket 1)
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, 0, 1, st, (const int *)B.bk, B.lab, B.cnt,
@@ -1659,7 +1659,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         } else {
             CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, ds, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
                         (const int *)B.sw, (const int *)B.bk, B.lab);
-            CPE_KLAUNCH(k_sw_touch, dim3((n * per + 255) / 256), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
+            CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, k + 1 < NTHR ? k + 1 : 0, st, (const int *)B.bk, B.lab, B.cnt,
                         (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
