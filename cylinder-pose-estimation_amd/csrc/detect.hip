@@ -283,8 +283,18 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
             forked = false;
         }
         M.lab_h = PL(int, P_LAB0); M.lab_v = PL(int, P_LAB1);
+        // the 7x7 blur of the indexing step only needs the region rectangle: it runs on the (now idle) spot stream beside
+        // the masks stage instead of behind it
+        if (X.ok) {
+            CPE_CHECK_HIP(hipEventRecord(X.fork, s));
+            CPE_CHECK_HIP(hipStreamWaitEvent(X.s2, X.fork, 0));
+            forked = true;
+            if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), X.s2)) != CPE_OK) return rc;
+            CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
+        }
         if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar)) != CPE_OK) return rc;
-        if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
+        if (X.ok) { CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join2, 0)); forked = false; }
+        else if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
         if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                               n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
                               std::max(h, w) + 128, s, planar)) != CPE_OK)
