@@ -23,7 +23,7 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st,
 int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s, int planar);
 int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
-                const RegionSide *side, int planar);
+                const RegionSide *side, int planar, hipStream_t sj);
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
@@ -283,17 +283,20 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
             forked = false;
         }
         M.lab_h = PL(int, P_LAB0); M.lab_v = PL(int, P_LAB1);
-        // the 7x7 blur of the indexing step only needs the region rectangle: it runs on the (now idle) spot stream beside
-        // the masks stage instead of behind it
+        // the 7x7 blur of the indexing step only needs the region rectangle, and only the lines kernel reads the joints: both
+        // run on the (now idle) spot stream beside the fragment chains of the masks stage
         if (X.ok) {
             CPE_CHECK_HIP(hipEventRecord(X.fork, s));
             CPE_CHECK_HIP(hipStreamWaitEvent(X.s2, X.fork, 0));
             forked = true;
             if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), X.s2)) != CPE_OK) return rc;
-            CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
         }
-        if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar)) != CPE_OK) return rc;
-        if (X.ok) { CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join2, 0)); forked = false; }
+        if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar, X.ok ? X.s2 : s)) != CPE_OK) return rc;   // joints: on s2 too
+        if (X.ok) {
+            CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
+            CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join2, 0));
+            forked = false;
+        }
         else if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
         if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                               n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),

@@ -1145,7 +1145,7 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
 // a-2/a-4 (joint centroids inside rect), a-5 (roi masks), a-6 (expansion).  Needs st[].rect and mc, the joints
 // components and the spot.
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
-                const RegionSide *side, int planar)
+                const RegionSide *side, int planar, hipStream_t sj)
 {
     const size_t total = (size_t)h * w * n;
     int rc;
@@ -1156,10 +1156,16 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     const size_t bit_words = (size_t)n * h * bit_row_words(w);
     const size_t fl_words = (size_t)h * bit_row_words(w) / 2;          // u64 words per frame of one flood plane
     auto fl_plane = [&](int k) { return reinterpret_cast<unsigned long long *>(B.bits + (size_t)(2 + k) * ((bit_words + 1) & ~(size_t)1)); };
-    // joints (their outer-background mask comes from the joints chain)
-    CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, s, B.joints_mask, h, w, B.roots_p, st, B.jtmp,
-                (const unsigned long long *)(B.fl_j + (size_t)n * h * ((w + 63) / 64)), (size_t)h * ((w + 63) / 64));
-    CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, s, st, B.jtmp, B.joints);
+    // joints (their outer-background mask comes from the joints chain).  Only the lines kernel reads them: with helper
+    // streams they are collected on `sj` beside the two fragment chains instead of in front of them
+    const bool jside = side && sj != s;
+    if (jside) { (void)hipEventRecord(side->clahe_done, s); (void)hipStreamWaitEvent(sj, side->clahe_done, 0); }
+    {
+        hipStream_t q = jside ? sj : s;
+        CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, q, B.joints_mask, h, w, B.roots_p, st, B.jtmp,
+                    (const unsigned long long *)(B.fl_j + (size_t)n * h * ((w + 63) / 64)), (size_t)h * ((w + 63) / 64));
+        CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, q, st, B.jtmp, B.joints);
+    }
     // a-5 tail, a-6 and the labelling of the expanded masks, once per line direction.  The two directions share
     // nothing but their inputs: the vertical one runs on the helper stream (if any) with the spot chain's label plane.
     const int rb_bands = (h + RB_R - 1) / RB_R;
