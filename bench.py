@@ -229,7 +229,9 @@ def pmc_traffic(kernel, images_per_launch):
     for fn in reversed(files):
         for r in csv.DictReader(open(fn)):
             if r['kernel'] == kernel:
-                per = float(r['fetch_KiB_per_launch_raw']) * 1024 + float(r['write_bytes_per_launch'])
+                # FETCH_SIZE is in KiB and under-reports reads by 2x on gfx950 (MI355X_MICROARCH.md; checked here on kernels that
+                # read a u8 plane exactly once: k_clahe_hist, k_clahe_apply, k_bitplanes64 report half of it) -> corrected column
+                per = float(r['fetch_bytes_x2_corrected']) + float(r['write_bytes_per_launch'])
                 return per * images_per_launch / float(r.get('images_per_launch', 64)), os.path.basename(fn)
     return None, None
 
@@ -386,7 +388,7 @@ def run_rank(args):
         roof = dict(kernel=short, calls_per_chunk=calls, images_per_launch=2 * c, avg_launch_ms=ms / calls,
                     share_of_gpu_time=ms / tot, launches_per_chunk=n_launch, traffic=traffic,
                     traffic_source=(f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, '
-                                    f'scaled to this launch size; not measured in this run') if traffic_src else None,
+                                    f'(FETCH x 1024 x 2 on gfx950 + WRITE), scaled to this launch size; not measured in this run') if traffic_src else None,
                     top5=[dict(kernel=r[0].split('::')[-1], calls=r[1], ms=round(r[2], 3)) for r in rep[:5]])
         if short == 'k_preprocess':
             # what bounds this kernel: f64 VALU.  `achieved` counts ALGORITHMIC operations only (one
