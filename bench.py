@@ -256,8 +256,8 @@ def make_frames(synth, torch, lo, hi, U, dev):
     plus noise realisation g // U (realisation 0 = the rendering itself; others: +-1 DN on ~1/3 of the pixels)"""
     base = synth.render_batch(U, H, W, seed=1000, device=dev, with_gt=False)
     n = hi - lo
-    left = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
-    right = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    stereo = torch.empty((n, 2, H, W), dtype=torch.uint8, device=dev)   # frame-major pairs: a chunk of frames is one
+    left, right = stereo[:, 0], stereo[:, 1]                             # contiguous run of images (read in place)
     g = torch.Generator(device=dev)
     b0, b1 = lo // U, (hi + U - 1) // U
     for b in range(b0, b1):

@@ -50,12 +50,29 @@ class FramePipeline:
             ws = self.ws[lane] = api.DetectWorkspace(n_img, self.h, self.w, self.device)
         return ws.use(n_img)
 
+    @staticmethod
+    def _interleaved(left, right):
+        """left = S[:, 0], right = S[:, 1] of one contiguous stereo tensor S [F,2,h,w] (frame-major pairs)?"""
+        h, w = left.shape[1:]
+        return (left.dim() == 3 and left.shape == right.shape and left.stride() == (2 * h * w, w, 1) and right.stride() == left.stride()
+                and right.data_ptr() == left.data_ptr() + h * w and left.untyped_storage().data_ptr() == right.untyped_storage().data_ptr())
+
     def run_chunk(self, left, right, lane=0, frame0=0):
         c = left.shape[0]
-        frames = torch.cat([left, right])                 # [2c,h,w]: one detect call for both cameras
-        det = api.detect_grid_batch(frames, self._ws(2 * c, lane))
-        g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
-        g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
+        if c > 0 and self._interleaved(left, right):
+            # the pairs already lie one after the other in memory: the detect call reads them in place (L0 R0 L1 R1 ...)
+            frames = torch.as_strided(left, (2 * c, self.h, self.w), (self.h * self.w, self.w, 1))
+            det = api.detect_grid_batch(frames, self._ws(2 * c, lane))
+            sl = lambda k, o: det[k][o::2].contiguous()
+            g1 = fit.GridTables(sl('xy', 0), sl('id', 0), sl('n', 0))
+            g2 = fit.GridTables(sl('xy', 1), sl('id', 1), sl('n', 1))
+            st_l, st_r = det['status'][0::2], det['status'][1::2]
+        else:
+            frames = torch.cat([left, right])             # [2c,h,w]: one detect call for both cameras (a copy)
+            det = api.detect_grid_batch(frames, self._ws(2 * c, lane))
+            g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
+            g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
+            st_l, st_r = det['status'][:c], det['status'][c:]
         rk = None if self.ransac is None else dict(self.ransac, frame0=int(self.ransac.get('frame0', 0)) + frame0)
         out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th,
                                             ransac=rk, mode=self.fit_mode)
@@ -64,7 +81,7 @@ class FramePipeline:
         rec[:, 6:12] = out['cyl'][:, 1]
         rec[:, 12:14] = out['fvals']
         rec[:, 14] = out['mean_err']
-        rec[:, 15] = pack_counters(out['m'], out['iters'][:, 0], out['status'], det['status'][:c], det['status'][c:])
+        rec[:, 15] = pack_counters(out['m'], out['iters'][:, 0], out['status'], st_l, st_r)
         return rec, det, out
 
     def run(self, left, right):

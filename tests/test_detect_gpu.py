@@ -158,6 +158,11 @@ def test_pipeline_records_and_profile(cpe, orc, gpu):
     assert all(r[2] >= 0 for r in rep)
     r2 = p2.run(L, R)
     assert torch.equal(r1, r2)                                      # ragged last chunk, same results
+    stereo = torch.stack([L, R], 1).contiguous()                    # frame-major pairs: read in place, no concatenation
+    assert p2._interleaved(stereo[:, 0], stereo[:, 1]) and not p2._interleaved(L, R)
+    for lanes in (1, 2):
+        p3 = pipeline.FramePipeline(480, 640, b['K1'], b['K2'], b['T21'], 45.0, chunk=2, device=gpu, lanes=lanes)
+        assert torch.equal(r1, p3.run(stereo[:, 0], stereo[:, 1]))
     n_pts, iters, fs, dl, dr = pipeline.unpack_counters(r1[:, 15])
     for i in range(3):
         a, c = S.detect_grid(b['left'][i].numpy()), S.detect_grid(b['right'][i].numpy())
