@@ -165,10 +165,30 @@ __device__ __forceinline__ unsigned long long col_mask64(int x0, int lo, int hi)
     return m & ~((1ull << a) - 1ull);
 }
 
+// where the word-level walks read the set from: the u8 image (compare with a threshold) or a one-bit plane of it that
+// already exists (cpe_dev.h BitWin layout: pixel x is bit x + 32 of its row; zero beyond the image) -- an eighth of the bytes
+struct ByteSrc {
+    const uint8_t *img; int w, thr, invert;
+    __device__ __forceinline__ ByteSrc frame(size_t f, int h) const { return ByteSrc{img + f * (size_t)h * w, w, thr, invert}; }
+    __device__ __forceinline__ unsigned long long pack(int y, int x0) const { return pack_row64(img + (size_t)y * w, x0, w, thr, invert); }
+    __device__ __forceinline__ bool px(int y, int x) const { return pred(img + (size_t)y * w, x, thr, invert); }
+};
+struct BitSrc {
+    const uint32_t *plane; int ws;
+    __device__ __forceinline__ BitSrc frame(size_t f, int h) const { return BitSrc{plane + f * (size_t)h * ws, ws}; }
+    __device__ __forceinline__ unsigned long long pack(int y, int x0) const
+    {
+        typedef unsigned long long u64a4 __attribute__((aligned(4)));
+        return *reinterpret_cast<const u64a4 *>(plane + (size_t)y * ws + (x0 >> 5) + 1);
+    }
+    __device__ __forceinline__ bool px(int y, int x) const { return (plane[(size_t)y * ws + ((x + 32) >> 5)] >> ((x + 32) & 31)) & 1u; }
+};
+
 // labels of a sparse pass: every pixel of the set points at the first pixel of its run inside the word; a run that
 // continues from the word to the left points at that word's last pixel instead (a chain of at most one link per word,
 // parents always smaller: the same forest the row-wise k_ccl_init builds, a few links deeper)
-__global__ __launch_bounds__(256) void k_ccl_init64(const uint8_t *__restrict__ img, int h, int w, int thr, int invert,
+template <class SRC>
+__global__ __launch_bounds__(256) void k_ccl_init64(SRC src0, int h, int w,
                                                     const FrameState *__restrict__ st, int use_rect, int *__restrict__ L)
 {
     const int WW = (w + 63) >> 6, strips = (h + CCL_STRIP - 1) / CCL_STRIP;
@@ -181,16 +201,15 @@ __global__ __launch_bounds__(256) void k_ccl_init64(const uint8_t *__restrict__ 
     if (r.x1 < r.x0 || x0 > r.x1 || x0 + 63 < r.x0) return;
     const int ya = max(sy * CCL_STRIP, r.y0), yb = min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1);
     const size_t N = (size_t)h * w;
-    const uint8_t *im = img + f * N;
+    const SRC src = src0.frame(f, h);
     int *Lf = L + f * N;
     const unsigned long long cmask = col_mask64(x0, r.x0, r.x1);
     const bool hasL = x0 - 1 >= r.x0;
     for (int y = ya; y <= yb; y++) {
-        const uint8_t *row = im + (size_t)y * w;
-        unsigned long long m = pack_row64(row, x0, w, thr, invert) & cmask;
+        unsigned long long m = src.pack(y, x0) & cmask;
         if (!m) continue;
         const int base = y * w + x0;
-        const bool cL = (m & 1ull) && hasL && pred(row, x0 - 1, thr, invert);
+        const bool cL = (m & 1ull) && hasL && src.px(y, x0 - 1);
         while (m) {
             const unsigned long long low = m & (0ull - m), run = m & ~(m + low);
             const int a = __ffsll((long long)low) - 1, e = a + __popcll(run);
@@ -206,8 +225,9 @@ __global__ __launch_bounds__(256) void k_ccl_init64(const uint8_t *__restrict__ 
 }
 
 // same unions as k_ccl_merge
-__global__ __launch_bounds__(256) void k_ccl_merge64(const uint8_t *__restrict__ img, int h, int w, int thr,
-                                                     int invert, int conn8, const FrameState *__restrict__ st, int use_rect,
+template <class SRC>
+__global__ __launch_bounds__(256) void k_ccl_merge64(SRC src0, int h, int w,
+                                                     int conn8, const FrameState *__restrict__ st, int use_rect,
                                                      int *__restrict__ L)
 {
     const int WW = (w + 63) >> 6, strips = (h + CCL_STRIP - 1) / CCL_STRIP;
@@ -221,17 +241,15 @@ __global__ __launch_bounds__(256) void k_ccl_merge64(const uint8_t *__restrict__
     const int ya = max(sy * CCL_STRIP, r.y0 + 1), yb = min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1);
     if (ya > yb) return;
     const size_t N = (size_t)h * w;
-    const uint8_t *im = img + f * N;
+    const SRC src = src0.frame(f, h);
     int *Lf = L + f * N;
     const unsigned long long cmask = col_mask64(x0, r.x0, r.x1);
     const bool hasL = x0 - 1 >= r.x0, hasR = x0 + 64 <= r.x1;
-    const uint8_t *row = im + (size_t)(ya - 1) * w;
-    unsigned long long A = pack_row64(row, x0, w, thr, invert) & cmask;
-    unsigned long long aL = (hasL && pred(row, x0 - 1, thr, invert)) ? 1ull : 0ull, aR = (hasR && pred(row, x0 + 64, thr, invert)) ? 1ull : 0ull;
+    unsigned long long A = src.pack(ya - 1, x0) & cmask;
+    unsigned long long aL = (hasL && src.px(ya - 1, x0 - 1)) ? 1ull : 0ull, aR = (hasR && src.px(ya - 1, x0 + 64)) ? 1ull : 0ull;
     for (int y = ya; y <= yb; y++) {
-        row = im + (size_t)y * w;
-        const unsigned long long C = pack_row64(row, x0, w, thr, invert) & cmask;
-        const unsigned long long cL = (hasL && pred(row, x0 - 1, thr, invert)) ? 1ull : 0ull, cR = (hasR && pred(row, x0 + 64, thr, invert)) ? 1ull : 0ull;
+        const unsigned long long C = src.pack(y, x0) & cmask;
+        const unsigned long long cL = (hasL && src.px(y, x0 - 1)) ? 1ull : 0ull, cR = (hasR && src.px(y, x0 + 64)) ? 1ull : 0ull;
         if (C) {
             const unsigned long long Cs = (C << 1) | cL, As = (A << 1) | aL;            // left, up-left
             const int base = y * w + x0;
@@ -251,7 +269,8 @@ __global__ __launch_bounds__(256) void k_ccl_merge64(const uint8_t *__restrict__
 }
 
 // component list of a roots-only pass: only the first pixel of a horizontal run can carry its own index
-__global__ __launch_bounds__(256) void k_ccl_roots64(const uint8_t *__restrict__ img, int h, int w, int thr, int invert,
+template <class SRC>
+__global__ __launch_bounds__(256) void k_ccl_roots64(SRC src0, int h, int w,
                                                      FrameState *__restrict__ st, int use_rect, const int *__restrict__ L,
                                                      int *__restrict__ roots, int cnt_sel)
 {
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256) void k_ccl_roots64(const uint8_t *__restrict__
     const int gi = blockIdx.x * 256 + threadIdx.x;
     const Rect r = get_rect(st, f, use_rect, h, w);
     const size_t N = (size_t)h * w;
-    const uint8_t *im = img + f * N;
+    const SRC src = src0.frame(f, h);
     const int *Lf = L + f * N;
     const int sy = gi / WW, j = gi - sy * WW, x0 = j * 64;
     const bool live = gi < WW * strips && !(r.x1 < r.x0 || x0 > r.x1 || x0 + 63 < r.x0);
@@ -272,9 +291,8 @@ __global__ __launch_bounds__(256) void k_ccl_roots64(const uint8_t *__restrict__
         const int y = ya + k;
         unsigned long long starts = 0;
         if (y <= yb) {
-            const uint8_t *row = im + (size_t)y * w;
-            const unsigned long long C = pack_row64(row, x0, w, thr, invert) & cmask;
-            const unsigned long long cL = (C & 1ull) && hasL && pred(row, x0 - 1, thr, invert) ? 1ull : 0ull;
+            const unsigned long long C = src.pack(y, x0) & cmask;
+            const unsigned long long cL = (C & 1ull) && hasL && src.px(y, x0 - 1) ? 1ull : 0ull;
             starts = C & ~((C << 1) | cL);
         }
         while (__ballot(starts != 0)) {
@@ -797,12 +815,12 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
     const bool words = (w % 16 == 0) && (((size_t)img & 15) == 0) && (((size_t)L & 15) == 0);
     const dim3 gwords((unsigned)((((w + 63) / 64) * ((h + CCL_STRIP - 1) / CCL_STRIP) + 255) / 256), n);
     if (words && sparse == 1 && !count_mode)
-        CPE_KLAUNCH(k_ccl_init64, gwords, dim3(256), 0, s, img, h, w, thr, invert, (const FrameState *)st, use_rect, L);
+        CPE_KLAUNCH(k_ccl_init64<ByteSrc>, gwords, dim3(256), 0, s, (ByteSrc{img, w, thr, invert}), h, w, (const FrameState *)st, use_rect, L);
     else
         CPE_KLAUNCH(k_ccl_init, dim3((rows + CCL_INIT_ROWS - 1) / CCL_INIT_ROWS), dim3(256), 0, s, img, rows, h, w, thr, invert, (const FrameState *)st, use_rect, L,
                     count_mode ? cnt : (int *)nullptr, sparse);
     if (words)
-        CPE_KLAUNCH(k_ccl_merge64, gwords, dim3(256), 0, s, img, h, w, thr, invert, conn8, (const FrameState *)st, use_rect, L);
+        CPE_KLAUNCH(k_ccl_merge64<ByteSrc>, gwords, dim3(256), 0, s, (ByteSrc{img, w, thr, invert}), h, w, conn8, (const FrameState *)st, use_rect, L);
     else
         CPE_KLAUNCH(k_ccl_merge, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, conn8,
                     (const FrameState *)st, use_rect, L);
@@ -813,7 +831,7 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
                     use_rect, touch);
     }
     if ((flags & 1) && words)
-        CPE_KLAUNCH(k_ccl_roots64, gwords, dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L, roots, cnt_sel);
+        CPE_KLAUNCH(k_ccl_roots64<ByteSrc>, gwords, dim3(256), 0, s, (ByteSrc{img, w, thr, invert}), h, w, st, use_rect, (const int *)L, roots, cnt_sel);
     else if (flags & 1)
         CPE_KLAUNCH(k_ccl_roots4, dim3((unsigned)((N + CCL_BLK_PX - 1) / CCL_BLK_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, (const int *)L,
                     roots, cnt_sel);
@@ -821,6 +839,23 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
         CPE_KLAUNCH(k_ccl_finish, dim3((unsigned)((N + CCL_FIN_PX - 1) / CCL_FIN_PX), n), dim3(256), 0, s, img, h, w, thr, invert, st, use_rect, L,
                     holes_only ? (const uint8_t *)touch : (const uint8_t *)nullptr, count_mode, cnt, roots, nrect, sparse, flags & 1, cnt_sel);
     CPE_CHECK_LAUNCH("ccl_run");
+    return CPE_OK;
+}
+
+// ccl_run(mask, ..., thr 0, 8-connected, sparse 1, CCL_ROOTS_ONLY) for a mask whose one-bit plane (build_bitplanes, 1 plane)
+// already exists: the three word-level walks read the plane.  Needs w % 16 == 0 and a 16-byte aligned label plane; the caller
+// falls back to ccl_run otherwise (returns CPE_ERR_ARG without launching).
+int ccl_roots_bits(const uint32_t *bits, int n, int h, int w, int *L, int *roots, int use_rect, FrameState *st, hipStream_t s, int cnt_sel)
+{
+    if (!((w % 16 == 0) && (((size_t)L & 15) == 0) && bits && roots)) return CPE_ERR_ARG;
+    CPE_LAUNCH_BEGIN();
+    CPE_KLAUNCH(k_ccl_ctl, dim3((n + 63) / 64), dim3(64), 0, s, st, (int *)nullptr, n, h, w, 0, cnt_sel);
+    const dim3 gwords((unsigned)((((w + 63) / 64) * ((h + CCL_STRIP - 1) / CCL_STRIP) + 255) / 256), n);
+    const BitSrc src{bits, bit_row_words(w)};
+    CPE_KLAUNCH(k_ccl_init64<BitSrc>, gwords, dim3(256), 0, s, src, h, w, (const FrameState *)st, use_rect, L);
+    CPE_KLAUNCH(k_ccl_merge64<BitSrc>, gwords, dim3(256), 0, s, src, h, w, 1, (const FrameState *)st, use_rect, L);
+    CPE_KLAUNCH(k_ccl_roots64<BitSrc>, gwords, dim3(256), 0, s, src, h, w, st, use_rect, (const int *)L, roots, cnt_sel);
+    CPE_CHECK_LAUNCH("ccl_roots_bits");
     return CPE_OK;
 }
 

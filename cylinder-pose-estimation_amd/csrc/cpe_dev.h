@@ -262,6 +262,7 @@ __device__ __forceinline__ unsigned nbr_mask(BitWin &bw, int x, int y) { return 
 
 // planes[t] = (img > thr0 + t * step), t < nplanes; plane stride per frame = nplanes_alloc * h * bit_row_words(w)
 int build_bitplanes(const uint8_t *img, int n, int h, int w, int thr0, int step, int nplanes, uint32_t *planes, hipStream_t s);
+int ccl_roots_bits(const uint32_t *bits, int n, int h, int w, int *L, int *roots, int use_rect, FrameState *st, hipStream_t s, int cnt_sel);
 
 // direction s = 0..7 counter-clockwise from east (x right, y down): DX = {1,1,0,-1,-1,-1,0,1}, DY = {0,-1,-1,-1,0,1,1,1},
 // stored as 2-bit fields (value + 1) so a step needs no table in memory

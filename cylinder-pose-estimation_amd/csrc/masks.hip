@@ -1187,8 +1187,10 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
         // roi = open3x3(mask & circle_mask & mask_contour), base = close3x3(roi)
         CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * rb_bands)), dim3(256), rb_lds, q, lm, (const uint8_t *)B.cm, (const uint8_t *)B.mc,
                     h, w, rb_bands, (const FrameState *)st, roi, base);
-        if ((rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel)) != CPE_OK) return rc;
         if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
+        rc = ccl_roots_bits(bits, n, h, w, lab, roots, 2, st, q, sel);         // labelling on the one-bit plane
+        if (rc == CPE_ERR_ARG) rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel);
+        if (rc != CPE_OK) return rc;
         unsigned long long *fl_bg = fl_plane(2 + 2 * which), *fl_out = fl_plane(3 + 2 * which);
         if ((rc = outside_flood(base, n, h, w, st, 2, fl_bg, fl_out, fl_words, q)) != CPE_OK) return rc;
         if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs, (const unsigned long long *)fl_out, fl_words);

@@ -1715,8 +1715,10 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
     CPE_KLAUNCH(k_discs, dim3(frame_waves(n, 4, MAXG / 4), n), dim3(256), 0, s, st, B.groups, h, w, B.ext);
-    if ((rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1)) != CPE_OK) return rc;
     if ((rc = build_bitplanes(B.ext, n, h, w, 0, 0, 1, B.bits, s)) != CPE_OK) return rc;
+    rc = ccl_roots_bits(B.bits, n, h, w, B.lab, B.roots, 0, st, s, 0);   // the labelling reads the one-bit plane (1/8 of the bytes)
+    if (rc == CPE_ERR_ARG) rc = ccl_run(B.ext, n, h, w, 0, 0, 1, B.lab, B.roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1);
+    if (rc != CPE_OK) return rc;
     CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best, 1);
     CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
