@@ -8,14 +8,14 @@ namespace cpe {
 constexpr int MAXROOTS = 131072;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
 // component lists of the blob sweep: one pool of (first pixel, count) entries per frame and list, the 17 thresholds one
 // after the other in the order they are filled (the first entry of a threshold = the sum of the counters of the ones before
-// it, region.hip sw_slot).  CLAHE turns sensor noise into specks: 1920x1200 frames with +-7..11 DN of noise were seen with
-// 200 000 dark components away from the border, 560 000 bright ones and 57 000 followed hole borders over all thresholds
-// (tools/overflow_census.py); clean frames stay below 30 000.
+// it, region.hip sw_slot).  CLAHE turns sensor noise into specks: 1920x1200 frames with +-7..11 DN of noise (and an intensity
+// ramp, tools/stress_parity.py) were seen with 770 000 dark components away from the border, 560 000 bright ones and 115 000
+// followed hole borders over all thresholds; clean frames stay below 30 000.
 enum { SWL_DARK = 0, SWL_BRIGHT = 1, SWL_TRACE = 2 };
 __host__ __device__ inline int sweep_pool(int h, int w, int which)
 {
     const long long N = (long long)h * w;
-    long long v = which == SWL_BRIGHT ? N / 2 : (which == SWL_DARK ? N / 4 : N / 8);   // twice the largest sums seen
+    long long v = which == SWL_TRACE ? N / 8 : N / 2;   // largest totals seen: 770 000 dark (noise + intensity ramp), 560 000 bright, 115 000
     const long long lo = which == SWL_TRACE ? (1 << 18) : (1 << 19);   // small frames: what 17 lists of 32768 entries held
     v = v < lo ? lo : (v > (1 << 23) ? (1 << 23) : v);
     return (int)((v + 255) / 256 * 256);
