@@ -297,7 +297,7 @@ def run_rank(args):
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
     auto_chunk = args.chunk <= 0
     if auto_chunk:
-        args.chunk = 192 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~245 MB (1920x1200) / ~730 MB (4K) of workspace
+        args.chunk = 192 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~280 MB (1920x1200) / ~765 MB (4K) of workspace
     if scaling == 'strong':
         total = args.frames
         lo, hi = D.shard_range(total, rank, world)

@@ -5,7 +5,7 @@
 namespace cpe {
 
 // ---------------------------------------------------------------- per-image state kept in the workspace
-constexpr int MAXROOTS = 131072;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
+constexpr int MAXROOTS = 262144;  // components per labelling pass and image (4K frames: ~48k noise specks in the joints mask)
 // component lists of the blob sweep: one pool of (first pixel, count) entries per frame and list, the 17 thresholds one
 // after the other in the order they are filled (the first entry of a threshold = the sum of the counters of the ones before
 // it, region.hip sw_slot).  CLAHE turns sensor noise into specks: 1920x1200 frames with +-7..11 DN of noise (and an intensity
@@ -21,10 +21,10 @@ __host__ __device__ inline int sweep_pool(int h, int w, int which)
     return (int)((v + 255) / 256 * 256);
 }
 constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
-constexpr int MAXB = 16384;      // blobs per threshold
-constexpr int MAXG = 16384;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
+constexpr int MAXB = 32768;      // blobs per threshold
+constexpr int MAXG = 32768;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
 constexpr int MAXG_LDS = 2048;   // ... whose middle centres sit in k_blob_merge's LDS (48 KB); the rest are read from HBM
-constexpr int GCAP = 64;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
+constexpr int GCAP = 48;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = 128;        // grid lines per direction (label groups of the joints: noise joints make extra ones)
 constexpr int MAXLP = 256;       // joints per label group (rows whose expanded masks touch share one: 4 x 39 seen on a 4K frame)

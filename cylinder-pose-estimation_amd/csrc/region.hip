@@ -636,13 +636,14 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
         const BlobRec *B = blobs_all + ((size_t)f * NTHR + thr) * MAXB;
         {   // rank by key (keys are distinct); the keys are staged in the list buffer, which is idle between thresholds
             int *keys = reinterpret_cast<int *>(&pl[0][0]);
-            static_assert(sizeof(pl) >= sizeof(int) * MAXB, "key staging");
-            for (int i = t; i < nb; i += MG_NT) keys[i] = B[i].key;
+            const bool staged = nb <= (int)(sizeof(pl) / sizeof(int));   // else: straight from the blob records
+            if (staged) for (int i = t; i < nb; i += MG_NT) keys[i] = B[i].key;
             __syncthreads();
             for (int i = t; i < nb; i += MG_NT) {
-                const int ki = keys[i];
+                const int ki = staged ? keys[i] : B[i].key;
                 int rank = 0;
-                for (int j = 0; j < nb; j++) rank += (keys[j] > ki) ? 1 : 0;
+                if (staged) { for (int j = 0; j < nb; j++) rank += (keys[j] > ki) ? 1 : 0; }
+                else { for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0; }
                 ord[rank] = i;
             }
         }

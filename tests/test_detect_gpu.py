@@ -322,3 +322,22 @@ def test_noisy_small_frames_fit_the_pooled_sweep_lists(cpe, gpu):
         torch.cuda.synchronize()
         for i, d in enumerate(det['ws'].state()):
             assert not (d['overflow'] & OVF_SWEEP), (seed, i, d['overflow'])
+
+
+@pytest.mark.gpu
+def test_heavy_sensor_noise_at_full_size_is_not_a_capacity_overflow(cpe, gpu):
+    """1920x1200 frames with uniform noise of +-7 .. +-11 DN (the frames of tools/overflow_census.py): CLAHE turns that noise
+    into tens of thousands of specks per threshold -- up to 24 000 blobs per threshold and 22 000 blob groups.  None of them
+    may end as status 6 (they did until the blob / group / component tables were doubled in round 2)."""
+    from cpe_amd import api, synth
+    b = synth.render_batch(5, 1200, 1920, seed=77, device='cuda', with_gt=False)
+    fr = torch.cat([b['left'], b['right']]).cpu().numpy().astype(np.int32)
+    rng = np.random.default_rng(5)
+    for i in range(fr.shape[0]):
+        a = 7 + i % 5
+        fr[i] += rng.integers(-a, a + 1, size=fr[i].shape)
+    det = api.detect_grid_batch(torch.from_numpy(np.clip(fr, 0, 255).astype(np.uint8)).to(gpu))
+    torch.cuda.synchronize()
+    st = det['ws'].state()
+    assert [int(s) for s in det['status']].count(6) == 0, [(int(s), d['overflow']) for s, d in zip(det['status'], st)]
+    assert max(d['n_groups'] for d in st) > 16384 or max(int(v) for v in det['ws'].plane('sweep')[:, 42:59].max(1).values) > 16384
