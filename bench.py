@@ -297,7 +297,7 @@ def run_rank(args):
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
     auto_chunk = args.chunk <= 0
     if auto_chunk:
-        args.chunk = 192 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~280 MB (1920x1200) / ~765 MB (4K) of workspace
+        args.chunk = 176 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~280 MB (1920x1200) / ~765 MB (4K) of workspace
     if scaling == 'strong':
         total = args.frames
         lo, hi = D.shard_range(total, rank, world)
@@ -306,7 +306,7 @@ def run_rank(args):
         lo, hi = rank * args.frames, (rank + 1) * args.frames
     F = hi - lo
     if auto_chunk and F > 0:
-        # equal chunks of at most 192 frames (measured: 170-190 frames per call is the sweet spot whatever the number of
+        # equal chunks of at most 176 frames (measured: 160-180 frames per call is the sweet spot whatever the number of
         # lanes -- 512 frames as 3 x 171: 2414 frames/s, as 4 x 128: 2247, as 2 x 256: 2317; an odd number of chunks on two
         # lanes costs nothing); a shard that fits one call of 256 frames is not split
         nch = 1 if F <= 256 and H * W <= 1920 * 1200 else -(-F // args.chunk)
