@@ -16,6 +16,8 @@ fails.  Default for N > 1 is --scaling strong = configs[3] ("4096-frame batch sh
 rank r owns the contiguous block dist.shard_range(F, r, N) (the loop of exp_gridDetection.m:78-81 cut in N pieces), no
 data-path collective, one RCCL all-gather of the 128-byte pose records closes each step.  --scaling weak gives every
 rank its own F frames.  Rank 0 prints ONE JSON line.
+--stage detect = configs[1] ("256-frame 1920x1200 batch, grid detection + triangulation only"): the same path stopped
+after chooseIdx + triangulate (fitSingleCylinder.m:12-17), F = 256 by default.
 """
 import argparse
 import json
@@ -68,26 +70,58 @@ def _free_port():
     return p
 
 
-def launch_ranks(argv, n):
-    """start n rank processes of this script (one per GPU), relay rank 0's stdout, fail if any rank fails.
-    The parent never makes a GPU call: children are ordinary child processes, nothing is re-executed."""
+def launch_ranks(argv, n, one_device_each=True, poll_s=0.2):
+    """start n rank processes of this script (one per GPU), relay rank 0's stdout, fail FAST if any rank fails: the
+    first non-zero exit terminates the other ranks (they would otherwise sit in a collective until the process-group
+    timeout) and the launcher returns non-zero; children are also ended when the parent leaves for any other reason.
+    The parent never makes a GPU call: children are ordinary child processes, nothing is re-executed.
+    one_device_each: rank r sees only GPU r (HIP_VISIBLE_DEVICES = the r-th entry of the parent's list, or r) and uses
+    cuda:0 -- a rank cannot touch another rank's card by mistake."""
+    import threading
     port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CPE_BENCH_CHILD='1')
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write(f'bench.py: rank(s) failed: {bad}\n')
-        return 1
-    return 0
+    parent_list = [v for v in os.environ.get('HIP_VISIBLE_DEVICES', '').split(',') if v.strip() != '']
+    procs, out0 = [], []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CPE_BENCH_CHILD='1')
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            if one_device_each:
+                env['HIP_VISIBLE_DEVICES'] = parent_list[r] if r < len(parent_list) else str(r)
+                env['CPE_BENCH_DEVICE'] = '0'
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        drain.start()
+        bad = []
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad or all(rc is not None for rc in rcs):
+                break
+            time.sleep(poll_s)
+        if bad:
+            sys.stderr.write(f'bench.py: rank(s) failed: {bad}; terminating the others\n')
+        return 1 if bad else 0
+    finally:
+        for p in procs:                      # whatever happened: no rank outlives the launcher
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        if procs:
+            try:
+                drain.join(timeout=5)
+            except Exception:
+                pass
+        if out0:
+            sys.stdout.write(out0[0].decode())
+            sys.stdout.flush()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -285,13 +319,19 @@ def run_rank(args):
     global H, W
     W, H = (int(v) for v in args.size.split('x'))
     backend = 'gloo' if args.stub else args.backend
-    rank, local, world = D.init_from_env(backend, device_index=None if args.stub else 0 if args.share_gpu else None)
+    if args.stub and os.environ.get('CPE_BENCH_FAIL_RANK') == os.environ.get('RANK', '0'):
+        raise SystemExit(3)                               # tests/test_dist_cpu.py: a rank that dies before the rendezvous
+    # this rank's GPU: LOCAL_RANK under torch.distributed.run (every rank sees all cards); 0 when bench.py's own launcher
+    # gave the rank one card (CPE_BENCH_DEVICE) or on the one-GPU rehearsal (--share-gpu)
+    one_dev = os.environ.get('CPE_BENCH_DEVICE')
+    dev_index = 0 if args.share_gpu else int(one_dev) if one_dev is not None else None
+    rank, local, world = D.init_from_env(backend, device_index=None if args.stub else dev_index)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if args.stub:
         dev = torch.device('cpu')
     else:
-        dev = torch.device(f'cuda:{0 if args.share_gpu else local}')
+        dev = torch.device(f'cuda:{local if dev_index is None else dev_index}')
         torch.cuda.set_device(dev)
         cpe_amd.lib.load()                               # no CPU fallback: fail loudly
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
@@ -325,7 +365,8 @@ def run_rank(args):
         del base
         pipe = pipeline.FramePipeline(H, W, K1, K2, T21, radius, chunk=min(args.chunk, max(F, 1)), device=dev,
                                       fit_mode=1 if (args.fit_mode == 'lm' or args.ransac) else 0, lanes=args.lanes,
-                                      ransac=dict(hypotheses=args.ransac, seed=2026, frame0=lo) if args.ransac else None)
+                                      ransac=dict(hypotheses=args.ransac, seed=2026, frame0=lo) if args.ransac else None,
+                                      stage=args.stage)
 
     def sync():
         if dev.type == 'cuda':
@@ -416,11 +457,13 @@ def run_rank(args):
         else:
             n_pts, iters, fit_st, dl, dr = pipeline.unpack_counters(allrec[:, 15])
             ok = ((fit_st == 0) & (dl == 0) & (dr == 0)).float().mean().item()
-            fit_txt = (f'RANSAC({args.ransac} hypotheses)-wrapped LM fit (build-defined, BASELINE.json configs[4])' if args.ransac
+            fit_txt = ('nothing else: grid detection + triangulation only, no cylinder fit (BASELINE.json configs[1])' if args.stage == 'detect'
+                       else f'RANSAC({args.ransac} hypotheses)-wrapped LM fit (build-defined, BASELINE.json configs[4])' if args.ransac
                        else f'fitCylinderWPts3 {"LM" if args.fit_mode == "lm" else "Nelder-Mead"} '
                             f'(BASELINE.json configs[{2 if world == 1 else 3}])')
             out['config'] = dict(workload=f'{total}-frame {W}x{H} stereo batch' + (f' sharded x{world}' if world > 1 else '') +
-                                          f', full detect (both images) + chooseIdx + triangulate + ' + fit_txt,
+                                          f', full detect (both images) + chooseIdx + triangulate + ' + fit_txt, stage=args.stage,
+                                 devices_visible=torch.cuda.device_count(), device=str(dev),
                                  frames_total=total, frames_per_gpu=F, chunk=min(args.chunk, F), lanes=args.lanes, unique_scenes=U, fit_mode=args.fit_mode,
                                  parallelism=f'contiguous frame shards x{world} (dist.shard_range), no data-path collective, '
                                              f'one all_gather of 128-B pose records per step', backend=backend, ranks=world)
@@ -429,7 +472,7 @@ def run_rank(args):
         out['all_gather_ms'] = gather_ms
         out['all_gather_bytes'] = int(total * 128)
         out['roofline'] = roof
-        if not args.stub and not args.no_cpu_baseline and not args.ransac and world == 1:
+        if not args.stub and not args.no_cpu_baseline and not args.ransac and world == 1 and args.stage == 'full':
             m = min(F, 64 * 4)
             out['cpu_baseline'] = cpu_baseline(left[:m].cpu().numpy(), right[:m].cpu().numpy(), K1, K2, T21, radius,
                                                gpu_rec=allrec[:m].cpu().numpy(), fit_mode=1 if args.fit_mode == 'lm' else 0)
@@ -445,12 +488,17 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--frames', type=int, default=4096,
-                    help='stereo frames of the batch (strong scaling: in total, sharded over the ranks; weak: per GPU)')
+    ap.add_argument('--frames', type=int, default=None,
+                    help='stereo frames of the batch (strong scaling: in total, sharded over the ranks; weak: per GPU); '
+                         'default 4096 (--stage full) / 256 (--stage detect)')
+    ap.add_argument('--stage', choices=['full', 'detect'], default='full',
+                    help='full = BASELINE.json configs[2] (detect + fit); detect = configs[1]: 256 frames, grid detection of both images + '
+                         'chooseIdx + triangulate, stop before fitCylinderWPts3 (fitSingleCylinder.m:12-17)')
     ap.add_argument('--scaling', choices=['strong', 'weak'], default=None,
                     help='default: strong for N > 1 (BASELINE.json configs[3]: the 4096-frame batch sharded N x)')
     ap.add_argument('--chunk', type=int, default=0,
-                    help='stereo frames per kernel batch (workspace size); 0 = 192 at 1920x1200, 56 at 3840x2160 (x --lanes in flight)')
+                    help='stereo frames per kernel batch (workspace size); 0 = equal chunks of at most 176 frames at 1920x1200 '
+                         '(171 for a 4096-frame shard), 56 at 3840x2160 (x --lanes in flight)')
     ap.add_argument('--lanes', type=int, default=2,
                     help='chunks in flight, each on its own HIP stream with its own workspace: the narrow tail of one chunk (fragments, '
                          'lines: one workgroup per image) runs beside the wide kernels of the next')
@@ -465,8 +513,10 @@ def main():
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 256 if args.stage == 'detect' else 4096
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus, one_device_each=not (args.share_gpu or args.stub)))
     run_rank(args)
 
 

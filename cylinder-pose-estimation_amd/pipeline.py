@@ -31,11 +31,14 @@ class FramePipeline:
     """reusable workspaces for chunks of `chunk` stereo frames of size h x w"""
 
     def __init__(self, h, w, K1, K2, T21, radius, chunk=64, device='cuda:0', selector=fit.SEL_CHOOSE_IDX, th=0.3,
-                 fit_mode=fit.FIT_NELDER_MEAD, lanes=1, ransac=None):
+                 fit_mode=fit.FIT_NELDER_MEAD, lanes=1, ransac=None, stage='full'):
         self.h, self.w, self.chunk, self.device = h, w, chunk, torch.device(device)
         self.K1, self.K2, self.T21, self.radius = K1, K2, T21, radius
         self.selector, self.th, self.fit_mode = selector, th, fit_mode
         self.ransac = ransac            # None, or keywords of fit.fit_cylinder_ransac_batch (build-defined config 5)
+        if stage not in ('full', 'detect'):
+            raise ValueError("stage is 'full' or 'detect'")
+        self.stage = stage              # 'detect': stop after chooseIdx + triangulate (fitSingleCylinder.m:12-17), no cylinder fit
         self.ws = {}
         # chunks are independent: `lanes` of them are in flight on their own HIP streams (each with its own
         # workspace), so the serial tails of one chunk (blob grouping, line fitting: one workgroup per frame)
@@ -73,6 +76,13 @@ class FramePipeline:
             g1 = fit.GridTables(det['xy'][:c], det['id'][:c], det['n'][:c])
             g2 = fit.GridTables(det['xy'][c:], det['id'][c:], det['n'][c:])
             st_l, st_r = det['status'][:c], det['status'][c:]
+        if self.stage == 'detect':      # BASELINE configs[1]: grid detection + triangulation only
+            out = fit.select_triangulate_batch(g1, g2, self.K1, self.K2, self.T21, self.selector, 3, self.th)
+            rec = torch.zeros((c, REC), dtype=torch.float64, device=frames.device)
+            rec[:, 14] = out['mean_err']
+            zero = torch.zeros_like(out['m'])
+            rec[:, 15] = pack_counters(out['m'], zero, zero, st_l, st_r)
+            return rec, det, out
         rk = None if self.ransac is None else dict(self.ransac, frame0=int(self.ransac.get('frame0', 0)) + frame0)
         out = fit.fit_single_cylinder_batch(g1, g2, self.K1, self.K2, self.T21, self.radius, self.selector, 3, self.th,
                                             ransac=rk, mode=self.fit_mode)

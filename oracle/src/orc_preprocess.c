@@ -10,9 +10,9 @@
  *       symmetric correlate1d summation order (centre tap, then pairs from the
  *       outermost inwards), np.gradient twice (central, one-sided at the border)
  *   hessian_matrix_eigvals            -> (a+c)/2 - sqrt(4 b^2 + (a-c)^2)/2   (smaller one)
- *   cv2.boxFilter 15x15 normalised, BORDER_REPLICATE on f64 (direct sums here: row
- *       then column, left->right / top->bottom; OpenCV's running sums are not
- *       reproducible in parallel -- documented deviation, parity unpinned)
+ *   cv2.boxFilter 15x15 normalised, BORDER_REPLICATE on f64: RowSum then ColumnSum in
+ *       OpenCV's update forms; the column sums run down the whole column as OpenCV's do,
+ *       the row sums restart every ORC_BOX_BX columns -- documented deviation, parity unpinned
  *
  * The Hessian half is PINNED bit-for-bit against the real skimage/scipy
  * (tests/golden/ridge_*.npz, tools/gen_golden.py).
@@ -136,15 +136,23 @@ ORC_API void orc_hessian_eigs(const double *G, int h, int w, double *emin, doubl
     free(gy);
 }
 
+/* Row-sum block of the box filter restatement below: cv2's RowSum<double,double> keeps ONE running sum along a whole
+ * image row (s += S[i + ksz] - S[i]), a sequential rounding history that no parallel evaluation reproduces.  The
+ * restatement restarts that sum every ORC_BOX_BX columns (counted from the image's left edge): the first output of a
+ * block is the direct 15-term sum, the next ORC_BOX_BX - 1 are OpenCV's update.  A constant of the specification, not of
+ * any kernel's thread blocking (deviation 1); tests/test_preprocess_cpu.py evaluates the literal
+ * whole-row form beside it and counts the mask pixels that differ. */
+#define ORC_BOX_BX 8
+
 /* sauvola_threshold_fast(b, 15, 0.5, 128) and the compare / invert of :1798-1800.
  * mask = 255 where b <= T (ridges), 0 where b > T. */
 ORC_API void orc_sauvola_mask(const double *b, int h, int w, uint8_t *mask)
 {
-    /* Box sums as cv2.boxFilter forms them (RowSum / ColumnSum of box_filter: a direct sum for the first output, then
-     * one value in and one out per step), with the running sums restarted every 8 columns / 4 rows (positions aligned to
-     * the image origin) so that blocks are independent: OpenCV's own sums run along the whole row / column, which no
-     * parallel evaluation reproduces bit for bit.  [ext], parity unpinned. */
-    const int r = 7, BX = 8, BY = 4;
+    /* cv2.boxFilter(b, CV_64F, (15,15), normalize=True, borderType=BORDER_REPLICATE), [ext] OpenCV 4.5.5 box_filter:
+     * RowSum (restarted every ORC_BOX_BX columns, see above), then ColumnSum exactly as OpenCV runs it: SUM starts at 0,
+     * takes the first ksize - 1 = 14 rows (7 replicas of row 0, rows 0..6) one after the other, then per output row
+     * s0 = SUM + Sp (row y + 7), D = s0 * scale, SUM = s0 - Sm (row y - 7), down the whole column.  parity unpinned. */
+    const int r = 7, BX = ORC_BOX_BX;
     const double scale = 1.0 / 225.0; /* 1./(ksize.width*ksize.height) */
     double *rs = (double *)malloc((size_t)h * w * sizeof(double));
     double *rs2 = (double *)malloc((size_t)h * w * sizeof(double));
@@ -170,21 +178,18 @@ ORC_API void orc_sauvola_mask(const double *b, int h, int w, uint8_t *mask)
     }
     for (int x = 0; x < w; x++) {
         double c = 0.0, c2 = 0.0;
+        for (int j = -r; j < r; j++) {      /* ColumnSum, sumCount == 0: SUM += Sp over the first ksize - 1 rows */
+            size_t o = (size_t)orc_clampi(j, 0, h - 1) * w + x;
+            c = c + rs[o];
+            c2 = c2 + rs2[o];
+        }
         for (int y = 0; y < h; y++) {
-            if (y % BY == 0) {
-                c = 0.0; c2 = 0.0;
-                for (int j = -r; j <= r; j++) {
-                    size_t o = (size_t)orc_clampi(y + j, 0, h - 1) * w + x;
-                    c = c + rs[o];
-                    c2 = c2 + rs2[o];
-                }
-            } else {           /* ColumnSum: SUM = s0 - Sm (after the previous output), s0 = SUM + Sp */
-                size_t oin = (size_t)orc_clampi(y + r, 0, h - 1) * w + x, oout = (size_t)orc_clampi(y - r - 1, 0, h - 1) * w + x;
-                c = (c - rs[oout]) + rs[oin];
-                c2 = (c2 - rs2[oout]) + rs2[oin];
-            }
-            double mean = c * scale;
-            double mean_sq = c2 * scale;
+            size_t oin = (size_t)orc_clampi(y + r, 0, h - 1) * w + x, oout = (size_t)orc_clampi(y - r, 0, h - 1) * w + x;
+            double s0 = c + rs[oin], s1 = c2 + rs2[oin];     /* s0 = SUM + Sp */
+            double mean = s0 * scale;
+            double mean_sq = s1 * scale;
+            c = s0 - rs[oout];                                /* SUM = s0 - Sm */
+            c2 = s1 - rs2[oout];
             double var = mean_sq - mean * mean;
             if (var < 0) var = 0;
             double sd = sqrt(var);

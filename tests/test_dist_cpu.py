@@ -98,6 +98,48 @@ def test_bench_weak_scaling_and_rank_failure():
     assert rc != 0 and out is None
 
 
+def test_launcher_fails_fast_when_a_rank_dies():
+    """rank 1 exits before the rendezvous: the launcher ends rank 0 (which would wait for it for minutes) and returns
+    non-zero quickly; no rank is left behind"""
+    import time
+    t0 = time.time()
+    rc, out, err = _bench('--gpus', '2', '--stub', '--frames', '8', '--steps', '1', '--warmup', '0', env=dict(CPE_BENCH_FAIL_RANK='1'))
+    assert rc != 0 and out is None
+    assert 'rank(s) failed' in err and time.time() - t0 < 60
+
+
+def test_launcher_gives_every_rank_one_device():
+    """HIP_VISIBLE_DEVICES of rank r = the r-th entry of the parent's list (or r); the stub ranks keep the parent's view"""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = []
+    real = subprocess.Popen
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            seen.append((env.get('RANK'), env.get('HIP_VISIBLE_DEVICES'), env.get('CPE_BENCH_DEVICE')))
+            self.stdout = open(os.devnull, 'rb')
+        def poll(self): return 0
+        def wait(self, timeout=None): return 0
+        def terminate(self): pass
+        def kill(self): pass
+    old_env = os.environ.get('HIP_VISIBLE_DEVICES')
+    try:
+        subprocess.Popen = FakeProc
+        os.environ['HIP_VISIBLE_DEVICES'] = '4,6'
+        assert bench.launch_ranks([], 2) == 0
+        os.environ.pop('HIP_VISIBLE_DEVICES')
+        assert bench.launch_ranks([], 2) == 0
+        assert bench.launch_ranks([], 2, one_device_each=False) == 0
+    finally:
+        subprocess.Popen = real
+        if old_env is not None:
+            os.environ['HIP_VISIBLE_DEVICES'] = old_env
+    assert seen[:2] == [('0', '4', '0'), ('1', '6', '0')] and seen[2:4] == [('0', '0', '0'), ('1', '1', '0')]
+    assert seen[4][2] is None and seen[5][2] is None
+
+
 def test_bench_under_torchrun_form():
     """the driver's form: ranks started by torch.distributed.run, RANK / WORLD_SIZE in the environment"""
     import json
