@@ -38,9 +38,10 @@ HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/
 F64_OPS_PEAK = 256 * 64 * 2.4e9                     # 39.3e12 separate f64 add / mul per second
 # algorithmic f64 operations per pixel of k_preprocess = every filter output evaluated once per pixel:
 # img_as_float 1 + Gaussian 25 taps along y 37 + along x 37 (centre product, 12 x (pair sum, product, accumulate)) + five
-# np.gradient arrays 10 + eigenvalue 10 + 15x15 box of b and b^2 20 (square 1, row sums (14 + 7 x 2) / 8 and column sums
-# (14 + 3 x 2) / 4 per plane, two scalings) + Sauvola threshold and compare 9
-PRE_ALGO_OPS_PER_PX = 124
+# np.gradient arrays 10 + eigenvalue 10 + 15x15 box of b and b^2 14 (square 1, row sums (14 + 7 x 2) / 8 per plane, cv2's
+# running column sums 2 per plane, two scalings) + Sauvola threshold and compare 9.  (124 until round 3, when the column
+# sums were direct 15-term sums restarted every 4 rows.)
+PRE_ALGO_OPS_PER_PX = 118
 # algorithmic bytes of one launch (what the kernel must read + write once), DESIGN.md section 3.
 #   streaming kernels: bytes per pixel of the frames (or of the blob detector's working rectangle) they walk;
 #   list kernels: bytes of the records they consume / produce, from the per-frame counters of the same run.

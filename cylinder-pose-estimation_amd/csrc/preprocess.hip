@@ -5,7 +5,7 @@
 // One 512-thread workgroup owns a column strip of SW = 128 output columns of one frame and marches down it K = 4 rows
 // per step.  Every stage of the chain keeps only the rows its consumer still needs, as a ring in LDS (77 KB per
 // workgroup: two workgroups share a CU):
-//   gray   8 x 176 u8    x = sx0-24 ..   rows r-2 .. r+2 of the 5x5 binomial       (global loads issued a step ahead)
+//   gray   8 x 176 u8    x = sx0-24 ..   rows r-2 .. r+2 of the 5x5 binomial       (LDS-DMA, an interval ahead)
 //   blur5 32 x 176 u8    x = sx0-22 ..   integer, exact, BORDER_REFLECT_101; 0 outside the image (scipy: mode='constant')
 //   V      4 x 170 f64   x = sx0-21 ..   Gaussian sigma 3 along y (scipy applies axis 0 first), 25 taps
 //   G      8 x 146 f64   x = sx0-9  ..   Gaussian along x; rows r-2 .. r+2 of the two np.gradient passes
@@ -19,7 +19,7 @@
 // A step is two barrier intervals; the stages alternate between them and run side by side on different waves, each on
 // the rows its producer finished in the interval before (stage p of step s works on rows s*K - L_p ...):
 //   interval A: wave 0 row sums (P5) | waves 1-2 blur5 (P1) | waves 3-7 x-Gaussian (P3)
-//   interval B: waves 0-1 column sums + Sauvola + mask store (P6) | waves 2-4 y-Gaussian (P2) | waves 5-7 eigenvalue (P4), gray (P0)
+//   interval B: waves 0-1 column sums + Sauvola + mask store (P6) | waves 2-4 y-Gaussian (P2) | waves 5-7 eigenvalue (P4) | wave 7 gray (P0)
 // (with two workgroups per CU a wave gets about a quarter of its SIMD: an interval lasts as long as its longest role,
 //  ~16 cycles per instruction of it; the roles are cut so that the longest ones of A and B are as short as they get)
 // The kernel is bound by vector-ALU issue (rocprofv3 SQ_ACTIVE_INST_VALU: 3/4 of all SIMD cycles), so the work per stage
@@ -30,6 +30,7 @@
 // HBM traffic per frame: h*w read (+ 48 halo columns per strip, served by L2) + h*w written.
 #include "cpe_internal.h"
 #include <algorithm>
+#include <cstddef>
 #include <type_traits>
 
 namespace {
@@ -59,14 +60,16 @@ __constant__ double c_gw[13] = {
     0x1.763a210dfb305p-15};
 
 struct Smem {
+    alignas(16) uint8_t gray[GYR * GYW + 16];   // first: the LDS-DMA destination base (M0) is a 16-bit byte address.
+                                                // + slack: the last strip of P1 reads one dword past its row
+    alignas(16) uint8_t b5[B5R * B5W];
     alignas(16) double lut[256];          // (double)v * (1.0 / 255): img_as_float of a u8 value
     alignas(16) double v[K * VST];
     alignas(16) double g[GR * GST];
     alignas(16) double e[ER * EST];
     alignas(16) double rs[2 * RPL];
-    alignas(16) uint8_t gray[GYR * GYW + 16];   // + slack: the last strip of P1 reads one dword past its row
-    alignas(16) uint8_t b5[B5R * B5W];
 };
+static_assert(offsetof(Smem, b5) < 65536, "LDS-DMA destination");
 static_assert(sizeof(Smem) <= 80 * 1024, "two workgroups per CU");
 
 // items per stage and step
@@ -74,7 +77,7 @@ constexpr int N1 = K * 22;             // blur5: 8 outputs per item
 constexpr int N3 = K * (GW / 2);       // x-Gaussian: 2 outputs per item
 constexpr int N2 = VW;                 // y-Gaussian: K outputs per item
 constexpr int N0 = K * (GYW / 4);      // gray dwords
-static_assert(N1 <= 128 && N3 <= 320 && N2 <= 192 && N0 <= 192 && EW == 128 + 14 && GW % 2 == 0, "wave roles");
+static_assert(N1 <= 128 && N3 <= 320 && N2 <= 192 && N0 > 128 && N0 <= 192 && EW == 128 + 14 && GW % 2 == 0, "wave roles");
 
 // the blur5 ring slot of row r: rows 4m+2 .. 4m+5 share an aligned block of 4 slots (the y-Gaussian's 28-row window
 // starts at such a row, the binomial writes such a block)
@@ -119,49 +122,63 @@ __device__ unsigned long long g_stamps[8][5];
 #define STAMP(v) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(NT, 4) void k_preprocess(const uint8_t *__restrict__ gray, int h, int w, int strips,
-                                                      uint8_t *__restrict__ mask)
+// FAST: the strip's gray window lies inside the frame and its rows are 4-byte aligned (LDS-DMA of dwords); the two forms
+// are separate instantiations so that the byte loads of the other one (ordinary loads into registers, whose hazards the
+// compiler guards with vmcnt waits) put no wait into this one, where a wait would drain the DMA early
+template <bool FAST>
+__device__ __forceinline__ void preprocess_strip(Smem &s, const uint8_t *__restrict__ img, int h, int w, int sx0, uint8_t *__restrict__ out)
 {
-    __shared__ Smem s;
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int frame = blockIdx.x / strips, strip = blockIdx.x - frame * strips;
-    const int sx0 = strip * SW;
-    const uint8_t *img = gray + (size_t)frame * h * w;
-    uint8_t *out = mask + (size_t)frame * h * w;
     const double inv255 = 1.0 / 255;
+    constexpr bool fast = FAST;
 
     for (int i = tid0; i < 256; i += NT) s.lut[i] = (double)i * inv255;
     for (int i = tid0; i < B5R * B5W / 4; i += NT) reinterpret_cast<uint32_t *>(s.b5)[i] = 0u;   // rows above the frame
 
-    // P0: one dword of a gray row block per thread (waves 5-7), requested at the top of a step and stored into the ring at
-    // its end (two intervals later: the latency hides behind the wave's other work).  The loads are inline asm: hipcc
-    // touches a loaded byte (zero extension, copies at the loop's back edge) right behind the load, i.e. it waits there.
-    // Strips inside the frame with 4-byte aligned rows load dwords, the others four bytes at BORDER_REFLECT_101 addresses.
-    const bool p0_wave = wave >= 5;
-    const int q0 = tid0 - 320;
-    const int q0k = q0 / (GYW / 4), q0d = q0 - q0k * (GYW / 4);
-    const bool fast = ((w & 3) == 0) && ((((size_t)img) & 3) == 0) && sx0 - 24 >= 0 && sx0 - 24 + GYW <= w;
-    auto gray_fetch = [&](int row0, uint32_t &b0, uint32_t &b1, uint32_t &b2, uint32_t &b3) {
-        int r = row0 + q0k;
+    // P0: the next gray row block goes from global memory straight into the ring by LDS-DMA (global_load_lds: per-lane
+    // source address, destination = wave-uniform LDS base + lane x size; no register holds the data, the barrier at the
+    // end of the interval retires it): 3 dword instructions of wave 7, whose other roles are the lightest.  For strips
+    // inside the frame with 4-byte aligned rows; the byte form of the instruction writes a zero-extended dword per lane,
+    // so the other strips take the path below.
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    auto gray_row = [&](int row0, int k) -> const uint8_t * {
+        int r = row0 + k;
         if (row0 < 0 || row0 + K > h) r = cpe::reflect101(cpe::clampi(r, -2, h + 1), h);   // (uniform) first and last blocks only
-        const uint8_t *rowp = img + (size_t)r * w;
-        const int xb = sx0 - 24 + 4 * q0d;
-        // ONE asm statement for both forms (the branch is inside it): two statements in two branches meet in a phi, and the
-        // compiler resolves that with register copies right behind the loads -- copies of registers whose loads are pending
-        const uint8_t *p0 = rowp + (fast ? xb : cpe::reflect101(xb, w)), *p1 = rowp + cpe::reflect101(xb + 1, w);
-        const uint8_t *p2 = rowp + cpe::reflect101(xb + 2, w), *p3 = rowp + cpe::reflect101(xb + 3, w);
-        const int fast_s = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
-        asm volatile("s_cmp_lg_u32 %8, 0\n\t"
-                     "s_cbranch_scc1 .Lgf_dword_%=\n\t"
-                     "global_load_ubyte %0, %4, off\n\tglobal_load_ubyte %1, %5, off\n\t"
-                     "global_load_ubyte %2, %6, off\n\tglobal_load_ubyte %3, %7, off\n\t"
-                     "s_branch .Lgf_done_%=\n"
-                     ".Lgf_dword_%=:\n\t"
-                     "global_load_dword %0, %4, off\n"
-                     ".Lgf_done_%=:"
-                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(fast_s) : "memory", "scc");
+        return img + (size_t)r * w;
     };
+    auto gray_fetch = [&](int row0, int lane) {
+        uint8_t *dst = &s.gray[((row0 + 64) & (GYR - 1)) * GYW];        // K ring rows, contiguous (row0 is a multiple of K)
+        if (fast) {
+            if (wave == 7) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int q = t * 64 + lane;
+                    if (q < N0) {
+                        const int qk = q / (GYW / 4), qd = q - qk * (GYW / 4);
+                        __builtin_amdgcn_global_load_lds((gptr_t)(gray_row(row0, qk) + sx0 - 24 + 4 * qd), (lptr_t)(dst + 256 * t), 4, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    // the other strips (frame border inside the window, or rows not 4-byte aligned): bytes from BORDER_REFLECT_101 addresses,
+    // two per thread, loaded at the top of a step and stored into the ring in interval B
+    auto gray_load_bytes = [&](int row0, int tid, uint8_t &v0, uint8_t &v1) {
+        const int qk = tid / GYW, xq = tid - qk * GYW;
+        v0 = gray_row(row0, qk)[cpe::reflect101(sx0 - 24 + xq, w)];
+        if (tid < K * GYW - NT) {
+            const int i = tid + NT, qk1 = i / GYW, xq1 = i - qk1 * GYW;
+            v1 = gray_row(row0, qk1)[cpe::reflect101(sx0 - 24 + xq1, w)];
+        }
+    };
+    auto gray_store_bytes = [&](int row0, int tid, uint8_t v0, uint8_t v1) {
+        uint8_t *dst = &s.gray[((row0 + 64) & (GYR - 1)) * GYW];
+        dst[tid] = v0;
+        if (tid < K * GYW - NT) dst[tid + NT] = v1;
+    };
+    static_assert(K * GYW > NT && K * GYW <= 2 * NT && GYW % 4 == 0, "gray block: at most two bytes per thread");
     __syncthreads();
 
     const bool xinner = sx0 - 9 >= 0 && sx0 + SW + 8 <= w - 1;   // P4: every column of the strip's b range has x-2 .. x+2 inside
@@ -209,8 +226,8 @@ __global__ __launch_bounds__(NT, 4) void k_preprocess(const uint8_t *__restrict_
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63;
-        uint32_t pre0, pre1, pre2, pre3;
-        if (p0_wave && q0 < N0) gray_fetch(base - L0, pre0, pre1, pre2, pre3);
+        uint8_t gb0 = 0, gb1 = 0;
+        if constexpr (!FAST) gray_load_bytes(base - L0, tid, gb0, gb1);
         STAMP(ta);
         // ------------------------------------------------------------------ interval A
         if (wave == 0) {
@@ -335,6 +352,8 @@ __global__ __launch_bounds__(NT, 4) void k_preprocess(const uint8_t *__restrict_
         STAMP(tc);
         STAMP(tm);
         // ------------------------------------------------------------------ interval B
+        if constexpr (FAST) gray_fetch(base - L0, lane);
+        else gray_store_bytes(base - L0, tid, gb0, gb1);
         if (wave < 2) {
             // P6: column sums (cv2 ColumnSum, running down the whole frame), Sauvola threshold, compare, store
             const int x = sx0 + tid;
@@ -462,17 +481,6 @@ __global__ __launch_bounds__(NT, 4) void k_preprocess(const uint8_t *__restrict_
                 }
             }
         }
-        // P0: the gray block requested at the top of the step goes into the ring
-        if (p0_wave && q0 < N0) {
-            const int row = base - L0 + q0k;
-            // the registers are written by loads the compiler does not know of: nothing may read (or copy) them
-            // before this wait, so the wait has no operands and the scheduler may not move anything across it
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t d = fast ? pre0 : (pre0 | (pre1 << 8) | (pre2 << 16) | (pre3 << 24));
-            reinterpret_cast<uint32_t *>(s.gray)[(((row + 64) & (GYR - 1)) * GYW) / 4 + q0d] = d;
-        }
         STAMP(td);
         __syncthreads();
         STAMP(te);
@@ -484,6 +492,19 @@ __global__ __launch_bounds__(NT, 4) void k_preprocess(const uint8_t *__restrict_
     if ((tid0 & 63) == 0)
         for (int k = 0; k < 5; k++) atomicAdd(&g_stamps[wave][k], tacc[k]);
 #endif
+}
+
+__global__ __launch_bounds__(NT, 4) void k_preprocess(const uint8_t *__restrict__ gray, int h, int w, int strips,
+                                                      uint8_t *__restrict__ mask)
+{
+    __shared__ Smem s;
+    const int frame = blockIdx.x / strips, strip = blockIdx.x - frame * strips;
+    const int sx0 = strip * SW;
+    const uint8_t *img = gray + (size_t)frame * h * w;
+    uint8_t *out = mask + (size_t)frame * h * w;
+    const bool fast = ((w & 3) == 0) && ((((size_t)img) & 3) == 0) && sx0 - 24 >= 0 && sx0 - 24 + GYW <= w;
+    if (fast) preprocess_strip<true>(s, img, h, w, sx0, out);
+    else preprocess_strip<false>(s, img, h, w, sx0, out);
 }
 
 }  // namespace
