@@ -20,14 +20,14 @@ __host__ __device__ inline int sweep_pool(int h, int w, int which)
     v = v < lo ? lo : (v > (1 << 23) ? (1 << 23) : v);
     return (int)((v + 255) / 256 * 256);
 }
-constexpr int MAXJ = 4096;       // joints kept inside the region rectangle
+constexpr int MAXJ = CPE_MAXJ;   // joints kept inside the region rectangle (include/cpe.h)
 constexpr int MAXB = 32768;      // blobs per threshold
 constexpr int MAXG = 32768;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
 constexpr int MAXG_LDS = 2048;   // ... whose middle centres sit in k_blob_merge's LDS (48 KB); the rest are read from HBM
 constexpr int GCAP = 48;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
-constexpr int MAXL = 128;        // grid lines per direction (label groups of the joints: noise joints make extra ones)
-constexpr int MAXLP = 256;       // joints per label group (rows whose expanded masks touch share one: 4 x 39 seen on a 4K frame)
+constexpr int MAXL = CPE_MAXL;   // grid lines per direction (label groups of the joints: noise joints make extra ones)
+constexpr int MAXLP = CPE_MAXLP; // joints per label group: a limit, not a slot size (the groups share one pool of MAXJ points)
 constexpr int MAXSEG = 2048;     // line fragments per mask in the expansion stage
 
 struct CompRec {        // one traced border

@@ -10,18 +10,25 @@
 
 namespace cpe {
 
+constexpr int ENT_CAP = 2 * CPE_MAXP;   // entries of the (col, row) table that are ranked; more than CPE_MAXP is an overflow anyway
+
 struct LinesWS {
-    double gpts[2][MAXL][MAXLP][2];  // joints per line (rows = side 0, cols = side 1)
+    // joints per label group: ONE pool per direction, the groups one after the other in order of first appearance
+    // (goff / gn), so a group may hold any share of the frame's joints; second half: the merged column lists of the
+    // planar script
+    double pool[2][2 * MAXJ][2];
     double ipts[2][MAXL][MAXL][2];   // intersections per line: at most one per line of the other direction
     double eq[2][MAXL][6];
     double ixy[MAXL][MAXL][2];
     double key[2][MAXL];
-    double ent_xy[MAXL * MAXL][2];
-    int ent_id[MAXL * MAXL][2];
-    int gn[2][MAXL], in[2][MAXL], glabel[2][MAXL];
+    double ent_xy[ENT_CAP][2];
+    int ent_id[ENT_CAP][2];
+    int gn[2][MAXL], goff[2][MAXL], in[2][MAXL], glabel[2][MAXL];
     unsigned char ival[MAXL][MAXL];
-    double fit_scr[2][MAXL][7 * MAXLP];   // per-line scratch of the fits: sorted abscissae / ordinates, QR columns
-    int fit_ord[2][MAXL][MAXLP];
+    double fit_scr[2][7 * MAXJ];     // scratch of the fits, 7 doubles per point of a line: sorted abscissae / ordinates, QR columns
+    int fit_ord[2][MAXJ];
+    int jlab[2][MAXJ];               // per joint and mask: label (union-find root) or -1, then its group and its rank in it
+    int jgrp[2][MAXJ], jrank[2][MAXJ];
     int fin_ord[2][MAXL], fin_n[2];  // lines that survive clean_and_relabel, in their final order (row1.., col1..)
 };
 
@@ -346,58 +353,91 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
 
     // group_points_by_label, groups in order of first appearance.
     // a) every thread resolves labels (union-find roots) of its share of the joints for both masks;
-    // b) wavefront 0 / 1 walk the joints of side 0 / 1 in order with one lane per group: a ballot finds the joint's group.
-    __shared__ int s_lab[2][MAXJ];
+    // b) wavefront 0 / 1 walk the joints of side 0 / 1 in order with one lane per group (four groups per lane): a ballot
+    //    finds the joint's group; the joint's rank in the group is the group's count at that moment;
+    // c) group offsets = prefix sums of the counts, every joint goes to pool[offset of its group + rank] (all threads).
     for (int i = t; i < nj; i += 256) {
         const int jx = J[2 * i], jy = J[2 * i + 1];
         const bool inb = !(jx < 0 || jx >= w || jy < 0 || jy >= h);
         for (int sd = 0; sd < 2; sd++) {
             int lab = -1;
             if (inb && E[sd][(size_t)jy * w + jx]) lab = uf_find(L[sd], jy * w + jx);   // else: background label / skipped
-            s_lab[sd][i] = lab;
+            W.jlab[sd][i] = lab;
         }
     }
     __syncthreads();
-    static_assert(MAXL == 128, "the grouping below gives every lane of a wavefront two groups");
+    static_assert(MAXL == 256, "the grouping below gives every lane of a wavefront four groups");
     if (t < 128) {
         const int sd = t >> 6, lane = t & 63;
-        int ng = 0, my_lab[2] = {-2, -2}, my_n[2] = {0, 0};   // lane k owns groups k and k + 64
+        int ng = 0, my_lab[4] = {-2, -2, -2, -2}, my_n[4] = {0, 0, 0, 0};   // lane k owns groups k, k + 64, k + 128, k + 192
         bool ovf = false;
         for (int i = 0; i < nj; i++) {
-            const int lab = s_lab[sd][i];
-            if (lab < 0) continue;
-            const unsigned long long mb0 = __ballot(lane < ng && my_lab[0] == lab);
-            const unsigned long long mb1 = __ballot(lane + 64 < ng && my_lab[1] == lab);
-            int g;
-            if (mb0) g = __ffsll((long long)mb0) - 1;
-            else if (mb1) g = 64 + __ffsll((long long)mb1) - 1;
-            else {
-                if (ng == MAXL) { ovf = true; continue; }
-                g = ng++;
-                if (lane == (g & 63)) { my_lab[g >> 6] = lab; my_n[g >> 6] = 0; }
+            const int lab = W.jlab[sd][i];
+            int g = -1, rank = 0;
+            if (lab >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned long long mb = __ballot(lane + 64 * q < ng && my_lab[q] == lab);
+                    if (g < 0 && mb) g = 64 * q + __ffsll((long long)mb) - 1;
+                }
+                if (g < 0) {
+                    if (ng == MAXL) ovf = true;
+                    else {
+                        g = ng++;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (lane == (g & 63) && (g >> 6) == q) { my_lab[q] = lab; my_n[q] = 0; }
+                    }
+                }
+                if (g >= 0) {
+                    int cnt = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if ((g >> 6) == q) cnt = my_n[q];
+                    rank = __shfl(cnt, g & 63);
+                    if (rank >= MAXLP) { ovf = true; g = -1; }
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (lane == (g & 63) && (g >> 6) == q) my_n[q]++;
+                    }
+                }
             }
-            if (lane == (g & 63)) {
-                int &cnt = my_n[g >> 6];
-                if (cnt < MAXLP) {
-                    W.gpts[sd][g][cnt][0] = (double)J[2 * i];
-                    W.gpts[sd][g][cnt][1] = (double)J[2 * i + 1];
-                    cnt++;
-                } else ovf = true;
-            }
+            if (lane == 0) { W.jgrp[sd][i] = g; W.jrank[sd][i] = rank; }
         }
-        if (lane < ng) { W.glabel[sd][lane] = my_lab[0]; W.gn[sd][lane] = my_n[0]; }
-        if (lane + 64 < ng) { W.glabel[sd][lane + 64] = my_lab[1]; W.gn[sd][lane + 64] = my_n[1]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (lane + 64 * q < ng) { W.glabel[sd][lane + 64 * q] = my_lab[q]; W.gn[sd][lane + 64 * q] = my_n[q]; }
         if (__ballot(ovf)) s_ovf = 1;
         if (lane == 0) s_ng[sd] = ng;
     }
     __syncthreads();
+    if (t == 0 || t == 64) {
+        const int sd = t >> 6;
+        int acc = 0;
+        for (int g = 0; g < s_ng[sd]; g++) { W.goff[sd][g] = acc; acc += W.gn[sd][g]; }
+    }
+    __syncthreads();
+    for (int i = t; i < nj; i += 256)
+        for (int sd = 0; sd < 2; sd++) {
+            const int g = W.jgrp[sd][i];
+            if (g < 0) continue;
+            double *p = W.pool[sd][W.goff[sd][g] + W.jrank[sd][i]];
+            p[0] = (double)J[2 * i];
+            p[1] = (double)J[2 * i + 1];
+        }
+    __syncthreads();
+    auto gp = [&](int sd, int slot) -> double (*)[2] { return W.pool[sd] + W.goff[sd][slot]; };
     // sort_rows: stable by min y (rows AND cols), then create_dummy_rows_cols + fit (degree 2)
-    if (t < 2 * MAXL) {
-        const int sd = t / MAXL, g = t % MAXL;
+    for (int idx = t; idx < 2 * MAXL; idx += 256) {
+        const int sd = idx / MAXL, g = idx % MAXL;
         if (g < s_ng[sd]) {
             const int n = W.gn[sd][g];
-            double m = W.gpts[sd][g][0][1];
-            for (int k = 1; k < n; k++) m = fmin(m, W.gpts[sd][g][k][1]);
+            double (*P)[2] = gp(sd, g);
+            double *scr = W.fit_scr[sd] + 7 * (size_t)W.goff[sd][g];
+            int *ord = W.fit_ord[sd] + W.goff[sd][g];
+            double m = P[0][1];
+            for (int k = 1; k < n; k++) m = fmin(m, P[k][1]);
             W.key[sd][g] = m;
             s_ord[sd][g] = g;
             for (int k = 0; k < 6; k++) W.eq[sd][g][k] = 0;
@@ -405,23 +445,22 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                 // degree 1; rows get their final +-50 domain, columns a provisional +-10 one (merged below)
                 if (n >= 2) {
                     double c[2], lo, hi;
-                    fit_line_sorted((const double (*)[2])W.gpts[sd][g], n, sd == 0 ? 0 : 1, c, lo, hi, W.fit_scr[sd][g], W.fit_ord[sd][g]);
+                    fit_line_sorted((const double (*)[2])P, n, sd == 0 ? 0 : 1, c, lo, hi, scr, ord);
                     const double mg = sd == 0 ? 50.0 : 10.0;
                     lo -= mg; hi += mg;
                     W.eq[sd][g][0] = c[0]; W.eq[sd][g][1] = c[1]; W.eq[sd][g][2] = lo; W.eq[sd][g][3] = hi; W.eq[sd][g][4] = fabs(lo - hi);
                 }
             } else if (n >= 3) {
-                double *tt = W.fit_scr[sd][g], *uu = tt + n;
-                int *ord = W.fit_ord[sd][g];
+                double *tt = scr, *uu = tt + n;
                 const int kc = sd == 0 ? 0 : 1;  // rows: y = f(x) sorted by x; cols: x = f(y) sorted by y
                 for (int i = 0; i < n; i++) ord[i] = i;
                 for (int a = 1; a < n; a++) {
                     int o = ord[a];
                     int b = a - 1;
-                    while (b >= 0 && W.gpts[sd][g][ord[b]][kc] > W.gpts[sd][g][o][kc]) { ord[b + 1] = ord[b]; b--; }
+                    while (b >= 0 && P[ord[b]][kc] > P[o][kc]) { ord[b + 1] = ord[b]; b--; }
                     ord[b + 1] = o;
                 }
-                for (int i = 0; i < n; i++) { tt[i] = W.gpts[sd][g][ord[i]][kc]; uu[i] = W.gpts[sd][g][ord[i]][1 - kc]; }
+                for (int i = 0; i < n; i++) { tt[i] = P[ord[i]][kc]; uu[i] = P[ord[i]][1 - kc]; }
                 double c[3];
                 polyfit2(tt, uu, n, c, tt + 2 * n);
                 double lo = tt[0] - 50, hi = tt[n - 1] + 50;
@@ -450,6 +489,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             for (int k = 0; k < n; k++) thr = fmax(thr, fabs(W.eq[1][s_ord[1][k]][4]));
             int m = 0;          // columns kept so far (s_ord[1][0..m))
             int k = 0;
+            int macc = MAXJ;    // merged lists go to the second half of the pool, one after the other
             while (k < n) {
                 const int slot = s_ord[1][k];
                 const double dk = fabs(W.eq[1][slot][4]);
@@ -458,21 +498,30 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                 double cum = dk;
                 int cnt = W.gn[1][slot];
                 int k2 = k + 1;
+                double (*D)[2] = W.pool[1] + macc;
+                {
+                    double (*P0)[2] = gp(1, slot);
+                    for (int q = 0; q < cnt; q++) { D[q][0] = P0[q][0]; D[q][1] = P0[q][1]; }
+                }
                 while (k2 < n) {
                     const int s2 = s_ord[1][k2];
                     const double d2 = fabs(W.eq[1][s2][4]);
                     if (!(d2 <= 0.9 * thr) || cum + d2 > thr) break;
                     cum += d2;
+                    double (*P2)[2] = gp(1, s2);
                     for (int q = 0; q < W.gn[1][s2]; q++) {
-                        if (cnt < MAXLP) { W.gpts[1][slot][cnt][0] = W.gpts[1][s2][q][0]; W.gpts[1][slot][cnt][1] = W.gpts[1][s2][q][1]; cnt++; }
+                        if (cnt < MAXLP) { D[cnt][0] = P2[q][0]; D[cnt][1] = P2[q][1]; cnt++; }
                         else s_ovf = 1;
                     }
                     k2++;
                 }
                 W.gn[1][slot] = cnt;
+                W.goff[1][slot] = macc;
+                macc += cnt;
                 if (cnt >= 2) {
                     double c[2], lo, hi;
-                    fit_line_sorted((const double (*)[2])W.gpts[1][slot], cnt, 1, c, lo, hi, W.fit_scr[1][slot], W.fit_ord[1][slot]);
+                    // (the fits of the single groups are done: their scratch is free)
+                    fit_line_sorted((const double (*)[2])D, cnt, 1, c, lo, hi, W.fit_scr[1], W.fit_ord[1]);
                     W.eq[1][slot][0] = c[0]; W.eq[1][slot][1] = c[1]; W.eq[1][slot][2] = lo; W.eq[1][slot][3] = hi; W.eq[1][slot][4] = fabs(lo - hi);
                     s_ord[1][m++] = slot;
                 }   // else: the members are deleted and nothing takes their place
@@ -483,8 +532,9 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                 const int slot = s_ord[1][q];
                 const int np = W.gn[1][slot];
                 if (np < 2) continue;
-                double lo = W.gpts[1][slot][0][1], hi = lo;
-                for (int i = 1; i < np; i++) { lo = fmin(lo, W.gpts[1][slot][i][1]); hi = fmax(hi, W.gpts[1][slot][i][1]); }
+                double (*P)[2] = gp(1, slot);
+                double lo = P[0][1], hi = lo;
+                for (int i = 1; i < np; i++) { lo = fmin(lo, P[i][1]); hi = fmax(hi, P[i][1]); }
                 lo -= 50; hi += 50;
                 W.eq[1][slot][2] = lo; W.eq[1][slot][3] = hi; W.eq[1][slot][4] = fabs(lo - hi);
             }
@@ -504,8 +554,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
         const int half = sp_window / 2;
         const uint8_t *gimg = gray + f * N;
         float *sbase = sp_scratch + (size_t)f * 2 * MAXL * 2 * sp_cap;
-        if (t < 2 * MAXL) {
-            const int sd = t / MAXL, pos = t % MAXL;
+        for (int l = t; l < 2 * MAXL; l += 256) {
+            const int sd = l / MAXL, pos = l % MAXL;
             int K = 0;
             if (pos < s_n[sd]) {
                 const double *eq = W.eq[sd][s_ord[sd][pos]];
@@ -514,7 +564,7 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
                     K = cntd > 0 ? (cntd > (double)sp_cap ? sp_cap + 1 : (int)cntd) : 0;
                 }
             }
-            s_K[t] = K;
+            s_K[l] = K;
         }
         __syncthreads();
         for (int l = 0; l < 2 * MAXL; l++) {
@@ -541,12 +591,12 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
             if (t == 0) S.status = CPE_ST_SUBPIXEL_RAISED;
             return;
         }
-        if (t < 2 * MAXL) {
-            const int K = s_K[t];
+        for (int l = t; l < 2 * MAXL; l += 256) {
+            const int K = s_K[l];
             if (K >= 3 && K <= sp_cap) {
-                const int sd = t / MAXL, pos = t % MAXL;
+                const int sd = l / MAXL, pos = l % MAXL;
                 double *eq = W.eq[sd][s_ord[sd][pos]];
-                const float *xs = sbase + (size_t)t * 2 * sp_cap, *ys = xs + sp_cap;
+                const float *xs = sbase + (size_t)l * 2 * sp_cap, *ys = xs + sp_cap;
                 double c[3];
                 polyfit2_stream(xs, ys, K, c);
                 float mn = xs[0], mx = xs[0];
@@ -571,8 +621,8 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     }
     __syncthreads();
     // per-line lists in loop order, and the clean_and_relabel keys (mean y for rows, mean x for cols)
-    if (t < 2 * MAXL) {
-        const int sd = t / MAXL, pos = t % MAXL;
+    for (int l = t; l < 2 * MAXL; l += 256) {
+        const int sd = l / MAXL, pos = l % MAXL;
         if (pos < s_n[sd]) {
             const int slot = s_ord[sd][pos];
             int k = 0;
@@ -709,6 +759,10 @@ __global__ __launch_bounds__(256) void k_lines(const int *__restrict__ lab_h, co
     const int total = s_total;
     if (total == 0) {
         if (t == 0) S.status = CPE_ST_EMPTY;
+        return;
+    }
+    if (total > CPE_MAXP) {     // more grid points than a table holds (include/cpe.h): CPE_ST_OVERFLOW, as in the oracle
+        if (t == 0) set_overflow(S, OVF_LINES);
         return;
     }
     for (int e = t; e < total; e += 256) {

@@ -74,7 +74,7 @@ class CpeRansacParams(C.Structure):
 
 
 MAXP = 2048
-MAXL = 128
+MAXL = 256
 
 
 def load():

@@ -214,3 +214,28 @@ def render_batch(n, h=1200, w=1920, seed=0, device='cpu', scene: Scene = None, w
     if with_gt:
         out['gt'] = ground_truth(scene, K1, K2, T21, Tp, fp, delta)
     return out
+
+
+def degrade(img, rng):
+    """random degradations of a rendered frame (tools/stress_parity.py, tests): exposure, uniform sensor noise, dead bands,
+    dark / saturated boxes, an intensity ramp.  Returns (u8 image, list of what was applied); the order of the draws from
+    `rng` is part of the contract (a seed names a frame)."""
+    f = img.astype(np.float64)
+    h, w = f.shape
+    what = []
+    if rng.random() < 0.6:
+        s = rng.uniform(0.45, 1.0); f *= s; what.append(f'exposure {s:.2f}')
+    if rng.random() < 0.5:
+        a = int(rng.integers(1, 12)); f += rng.integers(-a, a + 1, size=f.shape); what.append(f'noise {a}')
+    if rng.random() < 0.3:
+        x = int(rng.integers(w // 4, 3 * w // 4)); k = int(rng.integers(2, 9)); f[:, x:x + k] = 0; what.append('v band')
+    if rng.random() < 0.3:
+        y = int(rng.integers(h // 4, 3 * h // 4)); k = int(rng.integers(2, 9)); f[y:y + k, :] = 0; what.append('h band')
+    for _ in range(int(rng.integers(0, 4))):
+        y, x = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 40))
+        hh, ww = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        v = 255 if rng.random() < 0.4 else int(rng.integers(0, 60))
+        f[y:y + hh, x:x + ww] = v; what.append(f'box {v}')
+    if rng.random() < 0.2:
+        f += np.linspace(0, rng.uniform(20, 80), w)[None, :]; what.append('gradient')
+    return np.clip(f, 0, 255).astype(np.uint8), what

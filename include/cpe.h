@@ -122,7 +122,15 @@ CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t
  *   pts     f64[2, CPE_MAXL, CPE_MAXL, 2]  (x, y) in the reference's loop order
  *   n_lines i32[2]                         R, C  (0, 0 for a frame that failed before this stage)
  * All device buffers; asynchronous on `stream`. */
-#define CPE_MAXL 128
+#define CPE_MAXL 256
+/* Capacities of the line stage, part of the boundary: the reference's lists are unbounded (util_cylinder.py:376-389,
+ * 1106-1151); a frame with more joints inside the region rectangle than CPE_MAXJ, more label groups per direction than
+ * CPE_MAXL, more joints in one group than CPE_MAXLP or more grid points than CPE_MAXP ends with CPE_ST_OVERFLOW -- in this
+ * library AND in the test oracle (oracle/src/orc_lines.c reads these constants), so the two agree on every frame.
+ * Seen: 8 000 joints / 5 500 inside the rectangle / 250 groups / 255 joints in a group on 1920x1200 frames degraded with
+ * +-9 DN of noise and an intensity ramp (tools/stress_parity.py seeds 4011, 9508); clean frames: < 1 500 / < 64 / < 64. */
+#define CPE_MAXJ 16384
+#define CPE_MAXLP 1024
 CPE_API int32_t cpe_detect_line_tables(const void *ws, size_t ws_bytes, int32_t n, int32_t h, int32_t w, int32_t frame,
                                        double *eq, int32_t *npts, double *pts, int32_t *n_lines, void *stream);
 

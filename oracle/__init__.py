@@ -24,11 +24,18 @@ def build(force=False):
 
 
 def lib():
+    """ORACLE_ASAN=1: the AddressSanitizer + UBSan build (`make -C oracle asan`; the process must have been started with
+    LD_PRELOAD=libasan.so, see oracle/Makefile)"""
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, 'liboracle.so')
-        if not os.path.exists(so):
-            build()
+        if os.environ.get('ORACLE_ASAN') == '1':
+            so = os.path.join(_HERE, 'liboracle_asan.so')
+            if not os.path.exists(so):
+                subprocess.check_call(['make', '-s', '-C', _HERE, 'asan'], stdout=subprocess.DEVNULL)
+        else:
+            so = os.path.join(_HERE, 'liboracle.so')
+            if not os.path.exists(so):
+                build()
         _LIB = C.CDLL(so)
     return _LIB
 

@@ -6,16 +6,7 @@
  */
 #include "orc_common.h"
 
-#define ORC_MAXL 256
-#define ORC_MAXLP 256
-typedef struct {
-    int nlines;
-    int npts[ORC_MAXL];
-    double pts[ORC_MAXL][ORC_MAXLP][2];
-    double eq[ORC_MAXL][6];
-    int has_eq[ORC_MAXL];
-    int label[ORC_MAXL];
-} orc_lineset;
+#include "orc_lines.h"
 
 void orc_preprocess(const uint8_t *gray, int h, int w, uint8_t *blurred, uint8_t *mask, double *b_out);
 int orc_extract_joints(const uint8_t *binary, int h, int w, uint8_t *hmask, uint8_t *vmask, int *cent, int cap);
@@ -78,6 +69,7 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
     uint8_t *crop = NULL;
     int st = 0;
     *n_out = 0;
+    orc_capacity_overflow = 0;
 
     /* 1 */ orc_preprocess(gray, h, w, blurred, binary, NULL);
     /* 2 */ int nj = orc_extract_joints(binary, h, w, hmask, vmask, cent, capj);
@@ -93,6 +85,7 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
                 cyl[2 * ncyl] = cx; cyl[2 * ncyl + 1] = cy; ncyl++;
             }
         }
+        if (ncyl > CPE_MAXJ) { orc_capacity_overflow = 1; ncyl = CPE_MAXJ; }   /* include/cpe.h: capacity of the joint table */
         /* 5 */ st = orc_mask_roi_around_center(hmask, vmask, mc, gray, h, w, roi_h, roi_v, &r0, spot);
     }
     if (st == 0) {
@@ -123,6 +116,7 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
             orc_blur7(gray, h, w, g7);
             int n = orc_index_points(rows, cols, g7, h, w, r0, center, xy, id, cap);
             if (n < 0) st = -n;
+            else if (n > CPE_MAXP) orc_capacity_overflow = 1;   /* more grid points than a table of the boundary holds */
             else *n_out = n;
         }
     }
@@ -150,5 +144,6 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
     }
     free(blurred); free(binary); free(hmask); free(vmask); free(mc); free(roi_h); free(roi_v); free(exp_h); free(exp_v);
     free(g7); free(cent); free(cyl); free(rows); free(cols); free(lab_h); free(lab_v); free(crop);
+    if (orc_capacity_overflow) { st = ORC_ST_OVERFLOW; *n_out = 0; }   /* as the library: any exceeded capacity overrides the status */
     return st;
 }

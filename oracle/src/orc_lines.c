@@ -17,17 +17,9 @@
  */
 #include "orc_common.h"
 
-#define ORC_MAXL 256  /* lines per direction */
-#define ORC_MAXLP 256 /* points per line */
+#include "orc_lines.h"
 
-typedef struct {
-    int nlines;
-    int npts[ORC_MAXL];
-    double pts[ORC_MAXL][ORC_MAXLP][2];
-    double eq[ORC_MAXL][6];
-    int has_eq[ORC_MAXL]; /* clean_and_relabel keeps an equation only if it is not [0,0,0,0] (always kept: 6 long) */
-    int label[ORC_MAXL];  /* bookkeeping: original component label / running number */
-} orc_lineset;
+int orc_capacity_overflow = 0;
 
 ORC_API size_t orc_lineset_size(void) { return sizeof(orc_lineset); }
 
@@ -46,7 +38,7 @@ ORC_API void orc_group_points(const int *cent, int n, const int32_t *labels, int
         for (int k = 0; k < out->nlines; k++)
             if (out->label[k] == lab) { g = k; break; }
         if (g < 0) {
-            if (out->nlines == ORC_MAXL) continue;
+            if (out->nlines == ORC_MAXL) { orc_capacity_overflow = 1; continue; }
             g = out->nlines++;
             out->label[g] = lab;
             out->npts[g] = 0;
@@ -55,7 +47,7 @@ ORC_API void orc_group_points(const int *cent, int n, const int32_t *labels, int
             out->pts[g][out->npts[g]][0] = cent[2 * i];
             out->pts[g][out->npts[g]][1] = cent[2 * i + 1];
             out->npts[g]++;
-        }
+        } else orc_capacity_overflow = 1;
     }
     /* stable insertion sort by min y */
     int nl = out->nlines;

@@ -14,16 +14,7 @@
  */
 #include "orc_common.h"
 
-#define ORC_MAXL 256
-#define ORC_MAXLP 256
-typedef struct {
-    int nlines;
-    int npts[ORC_MAXL];
-    double pts[ORC_MAXL][ORC_MAXLP][2];
-    double eq[ORC_MAXL][6];
-    int has_eq[ORC_MAXL];
-    int label[ORC_MAXL];
-} orc_lineset;
+#include "orc_lines.h"
 
 typedef struct orc_contours orc_contours;
 orc_contours *orc_find_contours(const uint8_t *src, int h, int w, int mode, int method);
@@ -110,7 +101,7 @@ ORC_API int orc_get_convex_hull(const uint8_t *gray, int h, int w, int thr, int 
 /* np.polyfit(x, y, 1): Householder QR on the column-scaled n x 2 Vandermonde */
 static void polyfit1(const double *x, const double *y, int n, double *coef)
 {
-    double A[ORC_MAXL * 4][2], b[ORC_MAXL * 4], scale[2];
+    double A[ORC_MAXLP][2], b[ORC_MAXLP], scale[2];
     for (int i = 0; i < n; i++) { A[i][0] = x[i]; A[i][1] = 1.0; b[i] = y[i]; }
     for (int c = 0; c < 2; c++) {
         double s = 0;
@@ -118,7 +109,7 @@ static void polyfit1(const double *x, const double *y, int n, double *coef)
         scale[c] = sqrt(s);
         for (int i = 0; i < n; i++) A[i][c] /= scale[c];
     }
-    static double v[ORC_MAXL * 4];
+    static double v[ORC_MAXLP];
     for (int c = 0; c < 2; c++) {
         double nrm = 0;
         for (int i = c; i < n; i++) nrm += A[i][c] * A[i][c];
@@ -150,8 +141,8 @@ static void polyfit1(const double *x, const double *y, int n, double *coef)
 /* sort the n points by coordinate kc (stable), fit the other coordinate as a degree-1 polynomial of it */
 static void fit_sorted(const double (*pts)[2], int n, int kc, double *coef, double *lo, double *hi)
 {
-    static double t[ORC_MAXL * 4], u[ORC_MAXL * 4];
-    static int ord[ORC_MAXL * 4];
+    static double t[ORC_MAXLP], u[ORC_MAXLP];
+    static int ord[ORC_MAXLP];
     for (int i = 0; i < n; i++) ord[i] = i;
     for (int a = 1; a < n; a++) {
         int o = ord[a], b = a - 1;
@@ -201,7 +192,7 @@ ORC_API void orc_fit_lines_plane(orc_lineset *rows, orc_lineset *cols)
     }
     /* 5./5a. rebuild the column list: a merged column sits where its first member was */
     orc_lineset *out = (orc_lineset *)calloc(1, sizeof(orc_lineset));
-    static double mp[ORC_MAXL * 4][2];
+    static double mp[ORC_MAXLP][2];
     for (int g = 0; g < nc; g++) {
         if (gid[g] < 0) {
             int o = out->nlines++;
@@ -214,7 +205,10 @@ ORC_API void orc_fit_lines_plane(orc_lineset *rows, orc_lineset *cols)
         if (g > 0 && gid[g - 1] == gid[g]) continue;   /* not the first member of its group */
         int m = 0;
         for (int q = g; q < nc && gid[q] == gid[g]; q++)
-            for (int k = 0; k < cols->npts[q] && m < ORC_MAXL * 4; k++) { mp[m][0] = cols->pts[q][k][0]; mp[m][1] = cols->pts[q][k][1]; m++; }
+            for (int k = 0; k < cols->npts[q]; k++) {
+                if (m < ORC_MAXLP) { mp[m][0] = cols->pts[q][k][0]; mp[m][1] = cols->pts[q][k][1]; m++; }
+                else orc_capacity_overflow = 1;
+            }
         if (m < 2) continue;   /* the members were deleted, nothing takes their place */
         int o = out->nlines++;
         double c[2], lo, hi;
@@ -414,6 +408,7 @@ ORC_API int orc_detect_grid_plane(const uint8_t *gray, int h, int w, double *cen
     int32_t *lab_h = NULL, *lab_v = NULL;
     uint8_t *crop = NULL;
     *n_out = 0;
+    orc_capacity_overflow = 0;
     orc_preprocess(gray, h, w, blurred, binary, NULL);
     int nj = orc_extract_joints(binary, h, w, hmask, vmask, cent, capj);
     if (nj > capj) nj = capj;
@@ -427,6 +422,7 @@ ORC_API int orc_detect_grid_plane(const uint8_t *gray, int h, int w, double *cen
                 cyl[2 * ncyl] = cx; cyl[2 * ncyl + 1] = cy; ncyl++;
             }
         }
+        if (ncyl > CPE_MAXJ) { orc_capacity_overflow = 1; ncyl = CPE_MAXJ; }   /* include/cpe.h: capacity of the joint table */
         st = orc_mask_roi_around_center_ex(hmask, vmask, mc, gray, h, w, roi_h, roi_v, &r0, spot, 1);
     }
     if (st == 0) {
@@ -451,6 +447,7 @@ ORC_API int orc_detect_grid_plane(const uint8_t *gray, int h, int w, double *cen
         orc_blur7(gray, h, w, g7);
         int n = orc_index_points_plane(rows, cols, g7, h, w, r0, center, xy, id, cap);
         if (n < 0) st = -n;
+        else if (n > CPE_MAXP) orc_capacity_overflow = 1;
         else *n_out = n;
     }
     if (dbg) {
@@ -474,5 +471,6 @@ ORC_API int orc_detect_grid_plane(const uint8_t *gray, int h, int w, double *cen
     }
     free(blurred); free(binary); free(hmask); free(vmask); free(mc); free(roi_h); free(roi_v); free(exp_h); free(exp_v);
     free(g7); free(cent); free(cyl); free(rows); free(cols); free(lab_h); free(lab_v); free(crop);
+    if (orc_capacity_overflow) { st = ORC_ST_OVERFLOW; *n_out = 0; }
     return st;
 }

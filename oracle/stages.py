@@ -168,7 +168,7 @@ def connected_components(mask):
 
 
 # ---------------------------------------------------------------- line sets (a-8 .. a-14)
-MAXL, MAXLP = 256, 256
+MAXL, MAXLP = 256, 1024     # include/cpe.h: CPE_MAXL, CPE_MAXLP (oracle/src/orc_lines.h)
 
 
 class LineSet(C.Structure):

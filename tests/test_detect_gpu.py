@@ -14,7 +14,9 @@ def _frames(h, w, n, seed):
     return torch.cat([b['left'], b['right']])
 
 
-def _compare(cpe, orc, gpu, frames, check_planes=True, allow_overflow=False):
+def _compare(cpe, orc, gpu, frames, check_planes=True, allow_overflow=None):
+    """allow_overflow: {frame index: bit of FrameState.overflow} -- the ONLY frames that may end with CPE_ST_OVERFLOW where
+    the oracle has another status, each for the named capacity of the library's own workspace (cpe_dev.h OVF_*)"""
     from oracle import stages as S
     det = cpe.api.detect_grid_batch(frames.to(gpu))
     torch.cuda.synchronize()
@@ -34,8 +36,9 @@ def _compare(cpe, orc, gpu, frames, check_planes=True, allow_overflow=False):
             assert np.array_equal(planes['vmask'][i], ref['vmask']), tag
             assert np.array_equal(planes['clahe'][i], S.clahe(S.lab_l(npy[i]))), tag
             assert np.array_equal(planes['mask_contour'][i], ref['mask_contour']), tag
-        if allow_overflow and int(det['status'][i]) == 6:
-            continue            # build-defined: a fixed workspace capacity was exceeded (pathological frame)
+        if allow_overflow and i in allow_overflow and int(det['status'][i]) == 6:
+            assert state[i]['overflow'] == allow_overflow[i], (tag, state[i]['overflow'])
+            continue            # build-defined: that capacity of the workspace was exceeded (pathological frame)
         assert int(det['status'][i]) == ref['status'], (tag, state[i], ref['status'])
         if ref['status'] in (1,):
             continue
@@ -81,7 +84,7 @@ def test_detect_seed_sweep_with_degraded_frames(cpe, orc, gpu, seed):
     if seed % 2:
         f[1][:, w // 2 - 3:w // 2 + 3] = 0                                    # a dead band through the grid
     frames = torch.from_numpy(np.clip(f, 0, 255).astype(np.uint8))
-    _compare(cpe, orc, gpu, frames, check_planes=True, allow_overflow=False)
+    _compare(cpe, orc, gpu, frames, check_planes=True)
 
 
 @pytest.mark.gpu
@@ -99,7 +102,7 @@ def test_detect_4k_frame(cpe, orc, gpu):
     from cpe_amd import synth
     b = synth.render_batch(1, 2160, 3840, seed=17, device='cuda', with_gt=False)
     frames = torch.cat([b['left'], b['right']]).cpu()
-    n_ok = _compare(cpe, orc, gpu, frames, allow_overflow=False)
+    n_ok = _compare(cpe, orc, gpu, frames)
     assert n_ok >= 1
 
 
@@ -114,9 +117,42 @@ def test_detect_failure_statuses(cpe, orc, gpu):
     noise = rng.integers(0, 60, size=(480, 640), dtype=np.uint8)       # tens of thousands of specks: may overflow
     faint = rng.integers(5, 12, size=(480, 640), dtype=np.uint8)
     frames = torch.from_numpy(np.stack([dark, nospot, noise, f[1], faint]))
-    _compare(cpe, orc, gpu, frames, check_planes=False, allow_overflow=True)
+    # frame 2 (uniform noise 0..59 on every pixel): CLAHE turns it into thousands of specks per threshold, and some blob
+    # group of SimpleBlobDetector collects more than the 48 centres a group record holds (cpe_dev.h GCAP, OVF_GROUPS = 1024).
+    # The oracle's lists are unbounded there; it ends the frame with "no saturated spot".  Every other frame: exact status.
+    _compare(cpe, orc, gpu, frames, check_planes=False, allow_overflow={2: 1024})
     det = cpe.api.detect_grid_batch(frames.to(gpu))
     assert int(det['status'][3]) == 0 and int(det['n'][3]) > 0        # the good frame is unaffected by its neighbours
+
+
+@pytest.mark.gpu
+def test_degraded_full_size_frames_beyond_the_round_2_tables(cpe, orc, gpu):
+    """tools/stress_parity.py seeds 4011 and 9508 (1920x1200, +-8..9 DN of noise, an intensity ramp, boxes, a dead band): 8 000
+    joints, 4 100 / 5 500 of them inside the region rectangle, 220-250 label groups per direction.  Round 2's tables (4096
+    joints, 128 groups of 256) ended them with CPE_ST_OVERFLOW while the oracle made 660 / 1220 grid points of them; with
+    the capacities of include/cpe.h (one pool of joints shared by the groups) the two sides agree point for point."""
+    from cpe_amd import synth
+    frames = []
+    for seed in (4011, 9508):
+        rng = np.random.default_rng(seed)
+        b = synth.render_batch(1, 1200, 1920, seed=seed, with_gt=False)
+        d, _ = synth.degrade(b['left'][0].numpy(), rng)
+        frames.append(d)
+    n_ok = _compare(cpe, orc, gpu, torch.from_numpy(np.stack(frames)), check_planes=False)
+    assert n_ok == 2
+
+
+@pytest.mark.gpu
+def test_line_stage_capacities_are_the_same_on_both_sides(cpe, orc, gpu):
+    """a frame beyond a capacity of include/cpe.h ends with CPE_ST_OVERFLOW in the library and in the oracle alike: pure
+    noise over a rendered grid makes tens of thousands of joints"""
+    rng = np.random.default_rng(5)
+    f = _frames(600, 800, 1, 2).numpy().copy()
+    noisy = np.clip(f[0].astype(int) + rng.integers(-40, 41, size=f[0].shape), 0, 255).astype(np.uint8)
+    from oracle import stages as S
+    ref = S.detect_grid(noisy, debug=True)
+    det = cpe.api.detect_grid_batch(torch.from_numpy(noisy[None]).to(gpu))
+    assert int(det['status'][0]) == ref['status'], (det['ws'].state()[0], ref['status'], ref['n_joints'], ref['n_cyl_joints'])
 
 
 @pytest.mark.gpu

@@ -21,26 +21,7 @@ from oracle import stages as S
 SIZES = [(480, 640), (600, 800), (512, 768), (483, 650), (602, 801), (720, 1280)]
 
 
-def degrade(img, rng):
-    f = img.astype(np.float64)
-    h, w = f.shape
-    what = []
-    if rng.random() < 0.6:
-        s = rng.uniform(0.45, 1.0); f *= s; what.append(f'exposure {s:.2f}')
-    if rng.random() < 0.5:
-        a = int(rng.integers(1, 12)); f += rng.integers(-a, a + 1, size=f.shape); what.append(f'noise {a}')
-    if rng.random() < 0.3:
-        x = int(rng.integers(w // 4, 3 * w // 4)); k = int(rng.integers(2, 9)); f[:, x:x + k] = 0; what.append('v band')
-    if rng.random() < 0.3:
-        y = int(rng.integers(h // 4, 3 * h // 4)); k = int(rng.integers(2, 9)); f[y:y + k, :] = 0; what.append('h band')
-    for _ in range(int(rng.integers(0, 4))):
-        y, x = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 40))
-        hh, ww = int(rng.integers(8, 40)), int(rng.integers(8, 40))
-        v = 255 if rng.random() < 0.4 else int(rng.integers(0, 60))
-        f[y:y + hh, x:x + ww] = v; what.append(f'box {v}')
-    if rng.random() < 0.2:
-        f += np.linspace(0, rng.uniform(20, 80), w)[None, :]; what.append('gradient')
-    return np.clip(f, 0, 255).astype(np.uint8), what
+degrade = synth.degrade     # the degradations live beside the renderer: tests/test_detect_gpu.py replays single seeds
 
 
 def main():
