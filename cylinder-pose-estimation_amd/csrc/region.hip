@@ -985,12 +985,26 @@ __device__ __forceinline__ bool sw_prelinked(int p, int w, int lane)
     return p >= 0 && lane > 0 && prev == p - 1 && (p % w) != 0;
 }
 
-template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
-                                                  const FrameState *__restrict__ st, const int *__restrict__ sw,
-                                                  const int *__restrict__ bk, int *__restrict__ P)
+// The sweep kernels are launched on a one-dimensional grid of n * (blocks per frame) workgroups, frame after frame.
+// (Measured and dropped in round 3: giving every frame to the workgroups of ONE XCD -- ids = f mod 8, so that its parent
+//  plane and bucket lists sit in one 4 MiB L2 -- made k_sw_unite 10 % slower, 2698 against 2725 frames/s for the path: the
+//  unions and the agent-scope loads of the forest go past the L2 anyway, and eight frames at a time load the XCDs unevenly.)
+struct SwBlock { int f, bx, gx; };
+__device__ __forceinline__ SwBlock sw_block(int n, int per_frame)
 {
-    const size_t N = (size_t)h * w, f = blockIdx.y;
+    SwBlock r;
+    r.f = blockIdx.x / per_frame; r.bx = blockIdx.x - r.f * per_frame; r.gx = per_frame;
+    if (r.f >= n) r.f = -1;
+    return r;
+}
+inline unsigned sw_grid(int n, int per_frame) { return (unsigned)(n * per_frame); }
+
+template <bool DARK>
+__device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
+                                              const FrameState *__restrict__ st, const int *__restrict__ sw,
+                                              const int *__restrict__ bk, int *__restrict__ P)
+{
+    const size_t N = (size_t)h * w, f = vb.f;
     const int *S = sw + f * SW_STRIDE;
     const int nb = S[SW_BS + bucket];
     const int *list = bk + f * N + S[SW_BO + bucket];
@@ -1008,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_sw_unite(const uint8_t *__restrict__ im
     auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
     auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
     const int lane = threadIdx.x & 63;
-    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {   // wave-uniform: the shuffles below need every lane
+    for (int e0 = vb.bx * 256; e0 < nb; e0 += vb.gx * 256) {   // wave-uniform: the shuffles below need every lane
         const int e = e0 + threadIdx.x;
         const int i = e < nb ? list[e] : -2;
         const bool prel = sw_prelinked(i, w, lane);   // already points at its run's first pixel (k_sw_new, init pass)
@@ -1103,13 +1117,13 @@ __device__ __forceinline__ void sw_append(bool want, int value, int *counter, in
 // roots of components away from the rectangle border.  BRIGHT: flatten, list the ones that are roots, zero their
 // enclosed total.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int init_bucket, FrameState *__restrict__ st,
-                                                const int *__restrict__ bk, int *__restrict__ P, int *__restrict__ acc,
-                                                const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
-                                                int *__restrict__ sw, int cnt_base, int slot,
-                                                int *__restrict__ hpar, uint8_t *__restrict__ htime)
+__device__ __forceinline__ void sw_new_body(const SwBlock vb, int h, int w, int bucket, int init_bucket, FrameState *__restrict__ st,
+                                            const int *__restrict__ bk, int *__restrict__ P, int *__restrict__ acc,
+                                            const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
+                                            int *__restrict__ sw, int cnt_base, int slot,
+                                            int *__restrict__ hpar, uint8_t *__restrict__ htime)
 {
-    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const size_t N = (size_t)h * w, f = vb.f;
     const int lane = threadIdx.x & 63;
     const int *S = sw + f * SW_STRIDE;
     const int nb = S[SW_BS + bucket];
@@ -1122,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
         // the union with the left neighbour for them -- about half of all unions, each a memory-side atomic.
         const int ni = S[SW_BS + init_bucket];
         const int *li = bk + f * N + S[SW_BO + init_bucket];
-        for (int e0 = blockIdx.x * 256; e0 < ni; e0 += gridDim.x * 256) {
+        for (int e0 = vb.bx * 256; e0 < ni; e0 += vb.gx * 256) {
             const int e = e0 + threadIdx.x;
             const int p = e < ni ? li[e] : -2;
             const bool linked = sw_prelinked(p, w, lane);
@@ -1136,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
     if (bucket < 1) return;
     const int pool = sweep_pool(h, w, DARK ? SWL_DARK : SWL_BRIGHT);
     const int loff = sw_slot(S, cnt_base, slot, !DARK, pool).off;   // the counters of the other thresholds are at rest
-    for (int e0 = blockIdx.x * 256; e0 < nb; e0 += gridDim.x * 256) {
+    for (int e0 = vb.bx * 256; e0 < nb; e0 += vb.gx * 256) {
         const int e = e0 + threadIdx.x;
         const bool isnew = e < nb;
         int i = -1, root = -1;
@@ -1168,16 +1182,16 @@ __global__ __launch_bounds__(256) void k_sw_new(int h, int w, int bucket, int in
 // components of the previous step.  Still a root: keep (DARK: unless it now reaches the rectangle border).
 // Merged into another (DARK): hand its pixel count to the component that absorbed it.
 template <bool DARK>
-__global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, size_t src_frame_stride, int src_cap,
-                                                const int *__restrict__ src_cnt, int src_cnt_stride, int src_slot,
-                                                int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
-                                                int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
-                                                int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
-                                                int *__restrict__ hpar, uint8_t *__restrict__ htime)
+__device__ __forceinline__ void sw_old_body(const SwBlock vb, const int *__restrict__ src, size_t src_frame_stride, int src_cap,
+                                            const int *__restrict__ src_cnt, int src_cnt_stride, int src_slot,
+                                            int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
+                                            int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
+                                            int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                            int *__restrict__ hpar, uint8_t *__restrict__ htime)
 {
     // source: the list of threshold `src_slot` (the previous step) or, for the first dark step (src_slot < 0), the root list
     // of the run-based labelling (src: ints, src_frame_stride apart, src_cnt[f * src_cnt_stride] of them)
-    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const size_t N = (size_t)h * w, f = vb.f;
     const int *S = sw + f * SW_STRIDE;
     const int pool = sweep_pool(h, w, DARK ? SWL_DARK : SWL_BRIGHT);
     const int loff = sw_slot(S, cnt_base, slot, !DARK, pool).off;
@@ -1187,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
         const SwSlot ss = sw_slot(S, cnt_base, src_slot, !DARK, pool);
         ns = ss.cnt; es = 2; sp = reinterpret_cast<const int *>(lists + f * (size_t)pool + ss.off);
     } else { ns = min(src_cnt[f * src_cnt_stride], src_cap); sp = src + f * src_frame_stride; }
-    for (int k0 = blockIdx.x * 256; k0 < ns; k0 += gridDim.x * 256) {   // wave-uniform: sw_append is a wavefront collective
+    for (int k0 = vb.bx * 256; k0 < ns; k0 += vb.gx * 256) {   // wave-uniform: sw_append is a wavefront collective
     const int k = k0 + threadIdx.x;
     bool keep = false;
     int r = 0;
@@ -1214,17 +1228,17 @@ __global__ __launch_bounds__(256) void k_sw_old(const int *__restrict__ src, siz
 // wavefront of k_blob_trace walk borders of similar length.  A hole of n <= 3 pixels spans at most 1x3 or 2x2 pixels,
 // its border polygon runs through pixels 8-adjacent to it, so its area is at most 2x4 or 3x3 < 10 = minArea;
 // a hole of n >= 5000 pixels has a border polygon of area >= n >= maxArea.
-__global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
-                                                 int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
+__device__ __forceinline__ void sw_snap_body(const SwBlock vb, int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                             int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
 {
-    const size_t N = (size_t)h * w, f = blockIdx.y;
+    const size_t N = (size_t)h * w, f = vb.f;
     const int *S = sw + f * SW_STRIDE;
     const int pool = sweep_pool(h, w, SWL_DARK), pool_t = sweep_pool(h, w, SWL_TRACE);
     const SwSlot sl = sw_slot(S, cnt_base, slot, false, pool);
     const int cnt = sl.cnt;
     const int toff = trace ? sw_slot(S, SW_NT, slot, false, pool_t).off : 0;
     const int lane = threadIdx.x & 63;
-    for (int k0 = blockIdx.x * 256; k0 < cnt; k0 += gridDim.x * 256) {
+    for (int k0 = vb.bx * 256; k0 < cnt; k0 += vb.gx * 256) {
         const int k = k0 + threadIdx.x;
         const bool valid = k < cnt;
         int2 e = make_int2(0, 0);
@@ -1247,6 +1261,59 @@ __global__ __launch_bounds__(256) void k_sw_snap(int2 *__restrict__ lists, int *
             else set_overflow(st[f], OVF_SWEEP);
         }
     }
+}
+
+// The launches of a sweep step.  Per threshold the order is: unions of the pixels that join -> (dark) border marks ->
+// new roots + surviving old roots -> freeze the totals.  Steps that do not depend on each other share a launch (they are
+// independent workgroups of one grid): the totals of step t-1 are frozen beside the unions of step t (nothing changes a
+// total between the end of step t-1 and k_sw_new_old of step t), and the new and the old roots of a step are listed
+// together (both append to the same list through its atomic counter).  17 thresholds x 2 polarities: 87 launches
+// instead of 135, and the short list walks (a few hundred entries per frame) no longer pay a launch of their own.
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_unite_snap(int n, int g_unite, int g_snap,
+                                                       const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
+                                                       const FrameState *__restrict__ st, const int *__restrict__ bk, int *__restrict__ P,
+                                                       int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int snap_slot,
+                                                       const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ stw)
+{
+    SwBlock vb = sw_block(n, g_unite + g_snap);
+    if (vb.f < 0) return;
+    if (vb.bx < g_unite) {
+        vb.gx = g_unite;
+        sw_unite_body<DARK>(vb, img, h, w, lo, hi, bucket, st, (const int *)sw, bk, P);
+    } else {
+        vb.bx -= g_unite; vb.gx = g_snap;
+        sw_snap_body(vb, lists, sw, cnt_base, snap_slot, h, w, acc, trace, stw);
+    }
+}
+
+template <bool DARK>
+__global__ __launch_bounds__(256) void k_sw_new_old(int n, int g_new, int g_old, int h, int w, int bucket, int init_bucket,
+                                                    FrameState *__restrict__ st, const int *__restrict__ bk, int *__restrict__ P,
+                                                    int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
+                                                    int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                                    int *__restrict__ hpar, uint8_t *__restrict__ htime,
+                                                    const int *__restrict__ src, size_t src_frame_stride, int src_cap,
+                                                    const int *__restrict__ src_cnt, int src_cnt_stride, int src_slot)
+{
+    SwBlock vb = sw_block(n, g_new + g_old);
+    if (vb.f < 0) return;
+    if (vb.bx < g_new) {
+        vb.gx = g_new;
+        sw_new_body<DARK>(vb, h, w, bucket, init_bucket, st, bk, P, acc, touch, epoch, lists, sw, cnt_base, slot, hpar, htime);
+    } else {
+        vb.bx -= g_new; vb.gx = g_old;
+        sw_old_body<DARK>(vb, src, src_frame_stride, src_cap, src_cnt, src_cnt_stride, src_slot, h, w, st, P, acc, touch, epoch,
+                          lists, sw, cnt_base, slot, hpar, htime);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sw_snap(int n, int g_snap, int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
+                                                 int h, int w, const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ st)
+{
+    const SwBlock vb = sw_block(n, g_snap);
+    if (vb.f < 0) return;
+    sw_snap_body(vb, lists, sw, cnt_base, slot, h, w, acc, trace, st);
 }
 
 // groups with >= 2 centres -> key points -> filled discs (cv2.circle, Circle() midpoint spans)
@@ -1644,6 +1711,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     hipStream_t ds = side ? side->s : s;
     if (side) { (void)hipEventRecord(side->dark_done, s); (void)hipStreamWaitEvent(ds, side->dark_done, 0); }
     // ---- ascending thresholds: enclosed dark components (4-conn); B.hl[k] = (first pixel, pixel count)
+    const int g_bk = (int)gbk.x, g_list = (int)glist.x, g_roots = (int)frame_waves(n, 8, MAXROOTS / 256);
+    const int n_grid = n, nx = n;
     for (int k = 0; k < NTHR; k++) {
         const int thr = 50 + 10 * k, epoch = k + 1;
         if (k == 0) {
@@ -1651,26 +1720,25 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
             if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 2)) != CPE_OK) return rc;
             CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            // first entries of the pixels that join at the next step (bucket 1)
-            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, 0, 1, st, (const int *)B.bk, B.lab, B.cnt,
-                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
-            CPE_KLAUNCH(k_sw_old<true>, dim3(frame_waves(n, 8, MAXROOTS / 256), n), dim3(256), 0, ds, (const int *)B.roots, (size_t)MAXROOTS, (int)MAXROOTS, (const int *)&st[0].n_roots,
-                        (int)(sizeof(FrameState) / sizeof(int)), -1, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
-                        B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+            // first entries of the pixels that join at the next step (bucket 1) | the roots of the labelling that are holes
+            CPE_KLAUNCH(k_sw_new_old<true>, dim3(sw_grid(n_grid, g_bk + g_roots)), dim3(256), 0, ds, nx, g_bk, g_roots, h, w, 0, 1, st,
+                        (const int *)B.bk, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr,
+                        (uint8_t *)nullptr, (const int *)B.roots, (size_t)MAXROOTS, (int)MAXROOTS, (const int *)&st[0].n_roots,
+                        (int)(sizeof(FrameState) / sizeof(int)), -1);
         } else {
-            CPE_KLAUNCH(k_sw_unite<true>, gbk, dim3(256), 0, ds, (const uint8_t *)B.cl, h, w, thr - 10, thr, k, (const FrameState *)st,
-                        (const int *)B.sw, (const int *)B.bk, B.lab);
+            // unions of the pixels that join at this threshold | totals of the previous threshold frozen
+            CPE_KLAUNCH(k_sw_unite_snap<true>, dim3(sw_grid(n_grid, g_bk + g_list)), dim3(256), 0, ds, nx, g_bk, g_list, (const uint8_t *)B.cl, h, w,
+                        thr - 10, thr, k, (const FrameState *)st, (const int *)B.bk, B.lab, B.hl, B.sw, (int)SW_NH, k - 1,
+                        (const int *)B.cnt, B.tl, st);
             CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
-            CPE_KLAUNCH(k_sw_new<true>, gbk, dim3(256), 0, ds, h, w, k, k + 1 < NTHR ? k + 1 : 0, st, (const int *)B.bk, B.lab, B.cnt,
-                        (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
-            CPE_KLAUNCH(k_sw_old<true>, glist, dim3(256), 0, ds, (const int *)nullptr, (size_t)0, 0,
-                        (const int *)nullptr, 0, k - 1, h, w, st, B.lab, B.cnt, (const uint8_t *)B.touch, epoch,
-                        B.hl, B.sw, (int)SW_NH, k, (int *)nullptr, (uint8_t *)nullptr);
+            CPE_KLAUNCH(k_sw_new_old<true>, dim3(sw_grid(n_grid, g_bk + g_list)), dim3(256), 0, ds, nx, g_bk, g_list, h, w, k, k + 1 < NTHR ? k + 1 : 0, st,
+                        (const int *)B.bk, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr,
+                        (uint8_t *)nullptr, (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, k - 1);
         }
-        CPE_KLAUNCH(k_sw_snap, glist, dim3(256), 0, ds, B.hl, B.sw, (int)SW_NH, k, h, w, (const int *)B.cnt, B.tl, st);
         CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
+    CPE_KLAUNCH(k_sw_snap, dim3(sw_grid(n_grid, g_list)), dim3(256), 0, ds, nx, g_list, B.hl, B.sw, (int)SW_NH, NTHR - 1, h, w, (const int *)B.cnt, B.tl, st);
     {
         // hole borders of all thresholds and their radii
         if (!side && (rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
@@ -1684,19 +1752,18 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
     (void)hipMemsetAsync(B.htime, 0xFF, total, s);
-    CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
-                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0, B.hpar, B.htime);
+    CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
+                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0, B.hpar, B.htime,
+                (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, 0);
     for (int j = 0; j < NTHR; j++) {
         const int k = NTHR - 1 - j, thr = 50 + 10 * k;
         const int hi = j == 0 ? 255 : thr + 10;
-        CPE_KLAUNCH(k_sw_unite<false>, gbk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, thr, hi, k + 1, (const FrameState *)st,
-                    (const int *)B.sw, (const int *)B.bk, B.lab2);
-        CPE_KLAUNCH(k_sw_new<false>, gbk, dim3(256), 0, s, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
-                    (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
-        if (j > 0)
-            CPE_KLAUNCH(k_sw_old<false>, glist, dim3(256), 0, s, (const int *)nullptr, (size_t)0, 0,
-                        (const int *)nullptr, 0, k + 1, h, w, st, B.lab2, B.cnt2, (const uint8_t *)nullptr, j,
-                        B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime);
+        CPE_KLAUNCH(k_sw_unite_snap<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, (const uint8_t *)B.cl, h, w, thr, hi, k + 1,
+                    (const FrameState *)st, (const int *)B.bk, B.lab2, (int2 *)nullptr, B.sw, 0, 0, (const int *)nullptr, (int2 *)nullptr, st);
+        const int go = j > 0 ? g_list : 0;   // survivors of the previous (higher) threshold
+        CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk + go)), dim3(256), 0, s, nx, g_bk, go, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
+                    (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime,
+                    (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, k + 1);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
     if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
