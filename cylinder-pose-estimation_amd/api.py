@@ -47,14 +47,17 @@ class DetectWorkspace:
             _lib.load().cpe_detect_workspace_bytes(n, h, w) <= self.capacity
 
     def use(self, n):
-        """lay the buffer out for a batch of n frames (n <= the n it was made for)"""
+        """lay the buffer out for a batch of n frames (n <= the n it was made for).  Every use is a new generation of the
+        buffer's contents: a result dict remembers the generation it was made in, and the functions that read
+        intermediates through it (line_tables, frame_result) refuse a workspace that has served another call since."""
         if n != self.n:
             self.n = n
             self.bytes = _lib.load().cpe_detect_workspace_bytes(n, self.h, self.w)
+        self.generation = getattr(self, 'generation', 0) + 1
         return self
 
     def plane(self, name):
-        """intermediate of the last call: u8 [n,h,w] planes, i32 [n,4096,2] joints, or the state records"""
+        """intermediate of the last call: u8 [n,h,w] planes, i32 [n,CPE_MAXJ,2] joints, or the state records"""
         L = _lib.load()
         off = C.c_size_t(); per = C.c_size_t()
         _lib.check(L.cpe_detect_workspace_plane(self.n, self.h, self.w, PLANES[name], C.byref(off), C.byref(per)),
@@ -104,7 +107,7 @@ def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpix
                                           xy.data_ptr(), ids.data_ptr(), cnt.data_ptr(), center.data_ptr(),
                                           status.data_ptr(), torch.cuda.current_stream().cuda_stream),
                'cpe_detect_grid_batch_ex')
-    return dict(xy=xy, id=ids, n=cnt, center=center, status=status, ws=ws)
+    return dict(xy=xy, id=ids, n=cnt, center=center, status=status, ws=ws, ws_generation=ws.generation)
 
 
 def tables_of(det):
@@ -156,6 +159,9 @@ def line_tables(det, frame, target='cylinder'):
     reference's detect_grid (built by find_and_assign_intersections_P + clean_and_relabel, util_cylinder.py:1106-1206):
     {'points': {'row1': [(x, y), ...], ...}, 'equations': {'row1': [a2, a1, a0, lo, hi, span], ...}}"""
     ws = det['ws']
+    if det.get('ws_generation', ws.generation) != ws.generation:
+        raise RuntimeError('line_tables: the workspace of this result has served another detect call since (its line tables are '
+                           'gone); read them before the next call or give every result its own DetectWorkspace')
     dev = det['xy'].device
     ML = _lib.MAXL
     eq = torch.empty((2, ML, 6), dtype=torch.float64, device=dev)

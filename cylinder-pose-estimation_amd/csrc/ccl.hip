@@ -690,7 +690,7 @@ __device__ __forceinline__ unsigned long long flood_row(unsigned long long bg, u
     return f;
 }
 
-__global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict__ mask, int h, int w, const FrameState *__restrict__ st,
+__global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict__ mask, int h, int w, FrameState *__restrict__ st,
                                                       int use_rect, unsigned long long *__restrict__ bgw_all,
                                                       unsigned long long *__restrict__ out_all, size_t plane_words)
 {
@@ -746,7 +746,8 @@ __global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict_
     }
     // further sweeps, alternating direction, until nothing changes (this wavefront's own stores: visible to it in order;
     // a row's entry is only rewritten by the step that works on that row, so loading it a chunk early is safe)
-    for (int pass = 1; pass < 4096; pass++) {
+    bool converged = false;
+    for (int pass = 1; pass < FLOOD_MAX_PASSES; pass++) {
         const bool upw = pass & 1;
         bool any = false;
         prev = ~0ull;
@@ -782,11 +783,14 @@ __global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict_
                 prev = o;
             }
         }
-        if (!__ballot(any)) break;
+        if (!__ballot(any)) { converged = true; break; }
     }
+    // a background that still grows after FLOOD_MAX_PASSES alternating sweeps (a spiral thousands of turns deep) would
+    // leave components wrongly classified as nested: report the frame instead of altering it silently
+    if (!converged && lane == 0) set_overflow(st[f], OVF_TRACE);
 }
 
-int outside_flood(const uint8_t *mask, int n, int h, int w, const FrameState *st, int use_rect, unsigned long long *bgw,
+int outside_flood(const uint8_t *mask, int n, int h, int w, FrameState *st, int use_rect, unsigned long long *bgw,
                   unsigned long long *out, size_t plane_words, hipStream_t s)
 {
     CPE_CHECK_ARG(w <= 4096 && plane_words >= (size_t)h * ((w + 63) >> 6), "outside_flood: frame too wide or scratch too small");

@@ -131,7 +131,10 @@ __device__ __forceinline__ int *root_counter(FrameState &S, int sel)
 // outer-background mask of every frame's window (use_rect 0: the frame, 2: region rectangle + 2 px): out[f][y][j] bit b = pixel
 // (64 j + b, y) is background and 4-connected to the window border.  bgw / out: n * plane_words u64 of scratch each,
 // plane_words >= h * ceil(w / 64).
-int outside_flood(const uint8_t *mask, int n, int h, int w, const FrameState *st, int use_rect, unsigned long long *bgw,
+// Frames up to 4096 columns wide (one wavefront holds a row as 64 words of 64 pixels; wider frames are refused with
+// CPE_ERR_ARG by the callers' argument check).  A flood that has not converged after FLOOD_MAX_PASSES sweeps sets OVF_TRACE.
+constexpr int FLOOD_MAX_PASSES = 4096;
+int outside_flood(const uint8_t *mask, int n, int h, int w, FrameState *st, int use_rect, unsigned long long *bgw,
                   unsigned long long *out, size_t plane_words, hipStream_t s);
 // a component (raster-first pixel `root`) is external iff the pixel west of that pixel is outer background
 // (cv2.findContours(RETR_EXTERNAL) drops the components that lie in a hole of another one)

@@ -8,6 +8,7 @@
 // caller-supplied workspace (cpe_detect_workspace_bytes), laid out plane-major so that every kernel
 // streams [n, h, w] planes with fully coalesced accesses.
 #include "cpe_dev.h"
+#include <initializer_list>
 #include <mutex>
 #include <stdlib.h>
 #include <algorithm>
@@ -99,10 +100,31 @@ Layout make_layout(int n, int h, int w)
     per[P_HL] = (size_t)sweep_pool(h, w, SWL_DARK) * sizeof(int2);
     per[P_BL] = (size_t)sweep_pool(h, w, SWL_BRIGHT) * sizeof(int2);
     per[P_SUBPIX] = (size_t)2 * MAXL * 2 * (size_t)(std::max(h, w) + 128) * sizeof(float);
+    // Buffers whose lifetimes never overlap share memory (the call is three chains -- ridge mask / joints, saturated spot,
+    // region -- that run side by side and meet in the masks stage, then the lines stage; only buffers of ONE chain, or of
+    // stages separated by the join, may be paired):
+    //   border points + distance scratch of the blob tracers (read last by k_blob_median) | blob groups (k_blob_merge .. k_discs)
+    //   bright forest + its accumulator (dead after k_enclosed_all / the outer borders)   | the masks stage's eight u8 planes
+    //   label scratch of the joints and spot chains (the latter again in the masks stage) | the lines stage's tables
+    //   dark forest + its accumulator (dead when the dark sweep ends; the forest plane is used again for the region's own
+    //   labelling after k_discs, the two as the expanded masks' label planes)              | blob records (hole borders .. k_blob_merge)
+    // Planes 0 .. P_G7 are readable after the call (cpe_detect_workspace_plane): nothing is ever written over them later.
     size_t o = 0;
+    bool placed[P_COUNT] = {};
+    auto put = [&](std::initializer_list<int> a, std::initializer_list<int> b) {
+        size_t oa = o, ob = o;
+        for (int p : a) { L.off[p] = oa; oa += align_up(per[p] * (size_t)n, 256); placed[p] = true; }
+        for (int p : b) { L.off[p] = ob; ob += align_up(per[p] * (size_t)n, 256); placed[p] = true; }
+        o = std::max(oa, ob);
+    };
+    for (int i = 0; i < P_COUNT; i++) L.bytes_per_frame[i] = per[i];
+    put({P_DISTS, P_POOL}, {P_GROUPS});
+    put({P_LAB2, P_LAB3}, {P_ROI_H, P_ROI_V, P_BASE_H, P_BASE_V, P_EXP_H, P_EXP_V, P_TMPA, P_TMPB});
+    put({P_LABP, P_LABS}, {P_LINES, P_SUBPIX});
+    put({P_LAB0, P_LAB1}, {P_BLOBS});
     for (int i = 0; i < P_COUNT; i++) {
+        if (placed[i]) continue;
         L.off[i] = o;
-        L.bytes_per_frame[i] = per[i];
         o += align_up(per[i] * (size_t)n, 256);
     }
     L.total = o;

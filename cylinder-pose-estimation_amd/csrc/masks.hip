@@ -644,8 +644,10 @@ __device__ void line2z(uint8_t *img, int h, int w, long long p1x, long long p1y,
     }
 }
 
-// FillConvexPoly(shift = 16, colour 0)
-__device__ void fill_convex_poly_z(uint8_t *img, int h, int w, const long long *vx, const long long *vy, int npts)
+// FillConvexPoly(shift = 16, colour 0), the scan-line half: sink(y, x1, x2) receives every row span (x1 <= x2, clipped to
+// the image) in order of y.  OpenCV also draws the polygon's edges (Line2 from vertex to vertex): poly_edges_z below.
+template <class Sink>
+__device__ void convex_poly_rows(int h, int w, const long long *vx, const long long *vy, int npts, Sink sink)
 {
     const int shift = XY_SHIFT;
     struct { int idx, di; long long x, dx; int ye; } edge[2];
@@ -653,7 +655,6 @@ __device__ void fill_convex_poly_z(uint8_t *img, int h, int w, const long long *
     int i, y, imin = 0, edges = npts;
     long long xmin, xmax, ymin, ymax;
     const int delta1 = XY_ONE >> 1, delta2 = XY_ONE >> 1;
-    long long p0x = vx[npts - 1], p0y = vy[npts - 1];
     xmin = xmax = vx[0];
     ymin = ymax = vy[0];
     for (i = 0; i < npts; i++) {
@@ -662,8 +663,6 @@ __device__ void fill_convex_poly_z(uint8_t *img, int h, int w, const long long *
         if (py > ymax) ymax = py;
         if (px > xmax) xmax = px;
         if (px < xmin) xmin = px;
-        line2z(img, h, w, p0x, p0y, px, py);
-        p0x = px; p0y = py;
     }
     xmin = (xmin + delta) >> shift;
     xmax = (xmax + delta) >> shift;
@@ -709,7 +708,7 @@ __device__ void fill_convex_poly_z(uint8_t *img, int h, int w, const long long *
             if (xx2 >= 0 && xx1 < w) {
                 if (xx1 < 0) xx1 = 0;
                 if (xx2 >= w) xx2 = w - 1;
-                for (int x = xx1; x <= xx2; x++) img[(size_t)y * w + x] = 0;
+                sink(y, xx1, xx2);
             }
         }
         edge[0].x += edge[0].dx;
@@ -740,13 +739,15 @@ __device__ void circle_fill_z(uint8_t *im, int h, int w, int cx, int cy, int rad
     }
 }
 
-__device__ void ellipse_fill_z(uint8_t *img, int h, int w, int cx, int cy, int a, int b)
+// cv2.ellipse(img, (cx, cy), (a, b), 0, 0, 360, 0, -1): ellipse2Poly with the angle step OpenCV derives from the axes
+// (at most 360 / 5 + 2 vertices), rounded to 16 fractional bits as EllipseEx does; the polygon is then filled
+constexpr int ELL_MAXV = 80;
+__device__ int ellipse_vertices(int cx, int cy, int a, int b, long long *vx, long long *vy)
 {
     long long ccx = (long long)cx << XY_SHIFT, ccy = (long long)cy << XY_SHIFT;
     long long aw = llabs((long long)a << XY_SHIFT), ah = llabs((long long)b << XY_SHIFT);
     int delta = (int)(((aw > ah ? aw : ah) + (XY_ONE >> 1)) >> XY_SHIFT);
     delta = delta < 3 ? 90 : delta < 10 ? 30 : delta < 15 ? 18 : 5;
-    long long vx[400], vy[400];
     int nv = 0;
     long long prevx = -1, prevy = -1;
     bool have_prev = false;
@@ -767,35 +768,70 @@ __device__ void ellipse_fill_z(uint8_t *img, int h, int w, int cx, int cy, int a
         }
     }
     if (nv == 1) { vx[0] = vx[1] = ccx; vy[0] = vy[1] = ccy; nv = 2; }
-    fill_convex_poly_z(img, h, w, vx, vy, nv);
+    return nv;
 }
 
-// one thread per frame: contour of the largest saturated blob -> circle -> ellipse erased from cm (pre-set to 255)
+// one wavefront per frame: contour of the largest saturated blob -> circle -> ellipse erased from cm (pre-set to 255).
+// Lane 0 follows the border, runs minEnclosingCircle and makes the ellipse's vertices and row spans (a few hundred
+// sequential steps, all in LDS: no per-lane scratch); the pixels -- the polygon's edges, one lane per edge, and its rows,
+// 64 pixels per store -- are written by the whole wavefront.
+constexpr int SPOT_ROWS = 1024;   // row spans kept in LDS; a taller ellipse is filled by lane 0 alone
 __global__ __launch_bounds__(64) void k_spot_ellipse(const uint8_t *__restrict__ g19, int n, int h, int w,
                                                      const unsigned long long *__restrict__ best, FrameState *__restrict__ st,
                                                      int *__restrict__ verts /* n*MAXV*2 */, uint8_t *__restrict__ cm, int planar)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
+    const int f = blockIdx.x, lane = threadIdx.x;
     FrameState &S = st[f];
-    if (best[f] == 0) { S.spot_fail = 1; return; }
+    __shared__ long long s_vx[ELL_MAXV], s_vy[ELL_MAXV];
+    __shared__ int s_nv, s_rows, s_y0;
+    __shared__ int2 s_span[SPOT_ROWS];
     const size_t N = (size_t)h * w;
-    const int root = (int)(best[f] & 0xFFFFFF);
-    ThreshPred nz{g19 + f * N, w, h, 240};
-    VertVisitor vv{verts + (size_t)f * MAXV * 2, MAXV};
-    trace_border(nz, root % w, root / w, false, vv, 8 * (w + h) + (1 << 20));
-    if (vv.n > MAXV) { set_overflow(S, OVF_VERTS); vv.n = MAXV; }
-    float cx, cy, rad;
-    min_enclosing_circle(vv.v, vv.n, cx, cy, rad);
-    int icx = (int)cx, icy = (int)cy;
-    int cr0 = (int)rad;
-    int cr = rad < 30 ? cr0 + 20 : cr0 + 5;
-    int minor = cr + 20 > 1 ? cr + 20 : 1;
-    int a = (int)rint((cr + 40) / 2.0), b = (int)rint(minor / 2.0);
-    if (planar) { a = cr0; b = cr0; circle_fill_z(cm + f * N, h, w, icx, icy, cr0); }   // util_plane.py:2733-2792: plain circle
-    else ellipse_fill_z(cm + f * N, h, w, icx, icy, a, b);
-    S.r0 = cr0;
-    S.spot[0] = icx; S.spot[1] = icy; S.spot[2] = a; S.spot[3] = b;
+    uint8_t *img = cm + f * N;
+    if (lane == 0) {
+        s_nv = 0; s_rows = 0; s_y0 = 0;
+        if (best[f] == 0) S.spot_fail = 1;
+        else {
+            const int root = (int)(best[f] & 0xFFFFFF);
+            ThreshPred nz{g19 + f * N, w, h, 240};
+            VertVisitor vv{verts + (size_t)f * MAXV * 2, MAXV};
+            trace_border(nz, root % w, root / w, false, vv, 8 * (w + h) + (1 << 20));
+            if (vv.n > MAXV) { set_overflow(S, OVF_VERTS); vv.n = MAXV; }
+            float cx, cy, rad;
+            min_enclosing_circle(vv.v, vv.n, cx, cy, rad);
+            int icx = (int)cx, icy = (int)cy;
+            int cr0 = (int)rad;
+            int cr = rad < 30 ? cr0 + 20 : cr0 + 5;
+            int minor = cr + 20 > 1 ? cr + 20 : 1;
+            int a = (int)rint((cr + 40) / 2.0), b = (int)rint(minor / 2.0);
+            if (planar) { a = cr0; b = cr0; circle_fill_z(img, h, w, icx, icy, cr0); }   // util_plane.py:2733-2792: plain circle
+            else {
+                const int nv = ellipse_vertices(icx, icy, a, b, s_vx, s_vy);
+                s_nv = nv;
+                int rows = 0, y0 = 0;
+                convex_poly_rows(h, w, s_vx, s_vy, nv, [&](int y, int x1, int x2) {
+                    if (rows == 0) y0 = y;
+                    if (rows < SPOT_ROWS) s_span[rows] = make_int2(x1, x2);
+                    else for (int x = x1; x <= x2; x++) img[(size_t)y * w + x] = 0;
+                    rows++;
+                });
+                s_rows = rows < SPOT_ROWS ? rows : SPOT_ROWS; s_y0 = y0;
+            }
+            S.r0 = cr0;
+            S.spot[0] = icx; S.spot[1] = icy; S.spot[2] = a; S.spot[3] = b;
+        }
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    for (int e = lane; e < nv; e += 64) {          // FillConvexPoly draws every edge (vertex e-1 -> vertex e) with Line2
+        const int p = e == 0 ? nv - 1 : e - 1;
+        line2z(img, h, w, s_vx[p], s_vy[p], s_vx[e], s_vy[e]);
+    }
+    const int rows = s_rows, y0 = s_y0;
+    for (int r = 0; r < rows; r++) {
+        const int2 sp = s_span[r];
+        uint8_t *rowp = img + (size_t)(y0 + r) * w;
+        for (int x = sp.x + lane; x <= sp.y; x += 64) rowp[x] = 0;
+    }
 }
 
 // ---- line-fragment expansion ------------------------------------------------------------------------
@@ -874,6 +910,7 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     const int f = blockIdx.y;
     if (st[f].status != CPE_ST_OK) return;
     __shared__ unsigned long long s_win[BW_ROWS * 64];
+    __shared__ float s_pts[SEG_LPW][2 * MAXVS];
     const int ncomp = min(*root_counter(st[f], cnt_sel), MAXROOTS);
     // Few, long borders: a wavefront steps at the pace of its slowest lane, and with 64 borders in flight nearly every
     // step waits for some lane's window refill (one memory round trip).  SEG_LPW borders per wavefront keep most steps
@@ -884,7 +921,7 @@ __global__ __launch_bounds__(64) void k_seg_trace(const uint32_t *__restrict__ b
     if (!comp_is_external(outside + f * plane_words, w, root, window_x0(st[f], 2))) continue;   // RETR_EXTERNAL (:161)
     const int ws = bit_row_words(w);
     BitWin nz{base_bits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
-    float pts[2 * MAXVS];
+    float *pts = s_pts[threadIdx.x];     // the border's vertices live in LDS: 1.6 KB (5.6 KB planar) per lane were scratch
     SegVisitor sv{pts, MAXVS};
     if (!trace_border(nz, root % w, root / w, false, sv, 8 * (w + h) + (1 << 20))) { set_overflow(st[f], OVF_TRACE); continue; }
     const int n = sv.n;
@@ -1137,7 +1174,7 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
     if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab_s, B.roots_s, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 2)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_spot_area, dim3(4, n), dim3(64), 0, s, B.g19, h, w, B.roots_s, st, B.best_s);
     (void)hipMemsetAsync(B.cm, 255, total, s);
-    CPE_KLAUNCH(k_spot_ellipse, dim3((n + 63) / 64), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm, planar);
+    CPE_KLAUNCH(k_spot_ellipse, dim3(n), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm, planar);
     CPE_CHECK_LAUNCH("spot_stage");
     return CPE_OK;
 }

@@ -2,9 +2,9 @@
 
 The reference walks a folder one file at a time: imread -> cv2.undistort (which rebuilds its map per image) ->
 detect_grid -> imwrite, and dumps the decoded JSON of all images at the end (python_grid_detection_cylinder.py:12-64,
-python_grid_detection_plane.py:13-70).  Here the folder is read once, every camera's undistortion map is built once
-(iotool.Undistorter), the frames of a camera go through the remap kernel together and detect_grid_batch takes them in
-chunks.  Files written and the returned string are the reference's: `<stem>_arc<ext>` per image and
+python_grid_detection_plane.py:13-70).  Here the folder is walked in windows of a few dozen files: every camera's undistortion map is built
+once (iotool.Undistorter), the frames of a window go through the remap kernel and detect_grid_batch together, and their
+pictures are written before the next window is read.  Files written and the returned string are the reference's: `<stem>_arc<ext>` per image and
 `processed_images_data.json` = {stem: decoded result JSON}, indent 4."""
 import json
 import os
@@ -64,7 +64,13 @@ def undistort_group(images, und):
 
 def run_folder(json_path, folder_path, output_folder=None, target='cylinder', chunk=32, device='cuda:0'):
     """process_images_in_folder(json_path, folder_path, output_folder=None) -> JSON string (None for an empty folder).
-    A frame on which detect_grid fails stops the run with the TypeError the reference's tuple-unpack of None raises."""
+
+    The folder is walked in listing order in windows of `chunk` files: read -> undistort -> detect -> write, so host and
+    device memory are bounded by one window whatever the folder holds, and -- as in the reference's file-by-file loop --
+    the `_arc` pictures of the files before a failure are on disk when it is raised: a frame on which detect_grid fails
+    stops the run with the TypeError the reference's tuple-unpack of None raises, a file name without L / R with its
+    ValueError.  Undistortion maps (one per camera and frame size) and workspaces (one per frame size) are kept across
+    windows."""
     cams = dict(zip(('left', 'right'), iotool.load_camera_data(json_path)))
     dst = folder_path if output_folder is None else output_folder
     os.makedirs(dst, exist_ok=True)
@@ -72,42 +78,43 @@ def run_folder(json_path, folder_path, output_folder=None, target='cylinder', ch
     if not names:
         print(f'No images found in folder: {folder_path}')
         return None
-    keys = [camera_key(f) for f in names]
-    images = [read_image(os.path.join(folder_path, f)) for f in names]
-    # one undistortion map per (camera, frame size); one remap call per group
-    groups = {}
-    for i, (k, a) in enumerate(zip(keys, images)):
-        groups.setdefault((k,) + a.shape[:2], []).append(i)
-    frames = [None] * len(names)
-    for (k, h, w), members in groups.items():
-        und = iotool.Undistorter(cams[k], h, w, device)
-        g = undistort_group([images[i] for i in members], und)
-        for j, i in enumerate(members):
-            frames[i] = g[j]
-    # detect in chunks of equal-size frames (listing order inside a size class)
-    results = [None] * len(names)
-    by_size = {}
-    for i, f in enumerate(frames):
-        by_size.setdefault(tuple(f.shape), []).append(i)
-    for shape, members in by_size.items():
-        ws = None
-        for c0 in range(0, len(members), chunk):
-            part = members[c0:c0 + chunk]
-            batch = torch.stack([frames[i] for i in part])
-            if ws is None or not ws.fits(len(part), shape[0], shape[1]):
-                ws = api.DetectWorkspace(len(part), shape[0], shape[1], batch.device)
+    und_cache, ws_cache, collected = {}, {}, {}
+    for w0 in range(0, len(names), max(1, int(chunk))):
+        window = names[w0:w0 + max(1, int(chunk))]
+        keys, bad_name = [], None
+        for f in window:
+            try:
+                keys.append(camera_key(f))
+            except ValueError as e:                     # raised when the loop gets there: the files before it are processed
+                bad_name = e
+                break
+        window = window[:len(keys)]
+        images = [read_image(os.path.join(folder_path, f)) for f in window]
+        results = [None] * len(window)
+        groups = {}
+        for i, (k, a) in enumerate(zip(keys, images)):
+            groups.setdefault((k,) + a.shape[:2], []).append(i)
+        for (k, h, w), members in groups.items():
+            und = und_cache.get((k, h, w))
+            if und is None:
+                und = und_cache[(k, h, w)] = iotool.Undistorter(cams[k], h, w, device)
+            batch = undistort_group([images[i] for i in members], und)
+            ws = ws_cache.get((h, w))
+            if ws is None or not ws.fits(len(members), h, w):
+                ws = ws_cache[(h, w)] = api.DetectWorkspace(len(members), h, w, batch.device)
             det = api.detect_grid_batch(batch, ws, target=target)
             host = batch.cpu().numpy()
-            for j, i in enumerate(part):
+            for j, i in enumerate(members):             # (reads the line tables of this call before the workspace moves on)
                 results[i] = api.frame_result(det, j, host[j], target)
-    collected = {}
-    for name, res in zip(names, results):
-        if res is None:
-            raise TypeError(f'cannot unpack non-iterable NoneType object (detect_grid failed on {name})')
-        picture, result_json = res[0], res[1]
-        stem, ext = os.path.splitext(name)
-        collected[stem] = json.loads(result_json)
-        write_image(os.path.join(dst, f'{stem}_arc{ext}'), picture)
+        for name, res in zip(window, results):
+            if res is None:
+                raise TypeError(f'cannot unpack non-iterable NoneType object (detect_grid failed on {name})')
+            picture, result_json = res[0], res[1]
+            stem, ext = os.path.splitext(name)
+            collected[stem] = json.loads(result_json)
+            write_image(os.path.join(dst, f'{stem}_arc{ext}'), picture)
+        if bad_name is not None:
+            raise bad_name
     out_path = os.path.join(dst, 'processed_images_data.json')
     with open(out_path, 'w') as fh:
         json.dump(collected, fh, indent=4)

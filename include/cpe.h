@@ -152,7 +152,7 @@ CPE_API int32_t cpe_bgr2gray_batch(const uint8_t *bgr, int32_t n, int32_t h, int
 #define CPE_PLANE_ROI_V 5
 #define CPE_PLANE_EXP_H 6         /* u8[h,w]  expands_line_roi -> horizontal_expanded */
 #define CPE_PLANE_EXP_V 7
-#define CPE_PLANE_JOINTS 8        /* i32[4096,2] cylinder_centroids in contour order */
+#define CPE_PLANE_JOINTS 8        /* i32[CPE_MAXJ,2] cylinder_centroids in contour order */
 #define CPE_PLANE_STATE 9         /* per-frame state record (see csrc/cpe_dev.h FrameState) */
 #define CPE_PLANE_CLAHE 10        /* u8[h,w]  CLAHE'd L channel */
 #define CPE_PLANE_BLUR19 11       /* u8[h,w] */

@@ -1,6 +1,7 @@
 """The drop-in boundary beyond the point tables: the cylinder module's folder entry point, colour input,
 rows_updated / cols_updated, the .mat hand-off."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -67,12 +68,33 @@ def test_cylinder_entry_module_folder(cpe, orc, gpu, tmp_path):
     Image.fromarray(np.full((480, 640), 7, np.uint8)).save(src / 'zzL.png')
     with pytest.raises(TypeError):
         mod.process_images_in_folder(str(tmp_path / 'cam.json'), str(src), str(tmp_path / 'out3'))
+    # ... after the files in front of it have been written, as in the reference's file-by-file loop
+    listing = [f for f in os.listdir(src) if f.lower().endswith('.png')]
+    before = listing[:listing.index('zzL.png')]
+    assert all((tmp_path / 'out3' / (os.path.splitext(f)[0] + '_arc.png')).exists() for f in before)
+    assert not (tmp_path / 'out3' / 'processed_images_data.json').exists()
     empty = tmp_path / 'empty'; empty.mkdir()
     assert mod.process_images_in_folder(str(tmp_path / 'cam.json'), str(empty)) is None
     (src / 'zzL.png').unlink()
     Image.fromarray(b['left'][0].numpy()).save(src / 'camera0.png')          # neither L nor R in the name
     with pytest.raises(ValueError):
         mod.process_images_in_folder(str(tmp_path / 'cam.json'), str(src), str(tmp_path / 'out4'))
+
+
+@pytest.mark.gpu
+def test_line_tables_refuse_a_workspace_that_has_moved_on(cpe, orc, gpu):
+    """a result keeps a reference to its workspace; once that workspace has served another call (of any size) the line
+    tables of the older result are gone, and asking for them is an error instead of garbage"""
+    f = _frames(480, 640, 2, 0)
+    frames = torch.cat([f['left'], f['right']]).to(gpu)
+    ws = cpe.api.DetectWorkspace(4, 480, 640, frames.device)
+    det4 = cpe.api.detect_grid_batch(frames, ws)
+    rows4, cols4 = cpe.api.line_tables(det4, 3)
+    det1 = cpe.api.detect_grid_batch(frames[3:4], ws)             # the ragged last chunk of a folder: same buffer, new layout
+    rows1, cols1 = cpe.api.line_tables(det1, 0)
+    assert rows1 == rows4 and cols1 == cols4
+    with pytest.raises(RuntimeError):
+        cpe.api.line_tables(det4, 3)
 
 
 @pytest.mark.gpu
