@@ -85,13 +85,17 @@ class DetectWorkspace:
 
 
 def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpixel_step=1.0, target='cylinder'):
-    """frames: u8 tensor [n,h,w] on the GPU -> dict(xy f64[n,MAXP,2], id i32[n,MAXP,2], n i32[n], center f64[n,2],
-    status i32[n], ws).  target='plane': the planar-target script (python_grid_detection_plane.py, row f-2); ids are
-    (row, col) there."""
-    if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3):
-        raise TypeError('frames must be a CUDA uint8 tensor [n,h,w]')
+    """frames: u8 tensor [n,h,w] (grey) or [n,h,w,3] (BGR, as cv2.imread delivers) on the GPU -> dict(xy f64[n,MAXP,2],
+    id i32[n,MAXP,2], n i32[n], center f64[n,2], status i32[n], ws).  target='plane': the planar-target script
+    (python_grid_detection_plane.py, row f-2); ids are (row, col) there."""
+    if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8 and
+            (frames.dim() == 3 or (frames.dim() == 4 and frames.shape[3] == 3))):
+        raise TypeError('frames must be a CUDA uint8 tensor [n,h,w] (grey) or [n,h,w,3] (BGR)')
     frames = frames.contiguous()
-    n, h, w = frames.shape
+    colour = frames.dim() == 4
+    if colour and (target != 'cylinder' or subpixel):
+        frames = bgr_to_gray(frames); colour = False       # the planar script / the sub-pixel stage: luma only
+    n, h, w = frames.shape[:3]
     dev = frames.device
     L = _lib.load()
     if ws is None or not ws.fits(n, h, w) or ws.view.device != dev:
@@ -103,10 +107,11 @@ def detect_grid_batch(frames, ws=None, subpixel=False, subpixel_window=7, subpix
     center = torch.zeros((n, 2), dtype=torch.float64, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     prm = _lib.CpeDetectParams(1 if subpixel else 0, subpixel_window, subpixel_step, TARGETS[target], 0)
-    _lib.check(L.cpe_detect_grid_batch_ex(frames.data_ptr(), n, h, w, C.addressof(prm), ws.view.data_ptr(), ws.bytes,
-                                          xy.data_ptr(), ids.data_ptr(), cnt.data_ptr(), center.data_ptr(),
-                                          status.data_ptr(), torch.cuda.current_stream().cuda_stream),
-               'cpe_detect_grid_batch_ex')
+    entry = L.cpe_detect_grid_bgr_batch_ex if colour else L.cpe_detect_grid_batch_ex
+    _lib.check(entry(frames.data_ptr(), n, h, w, C.addressof(prm), ws.view.data_ptr(), ws.bytes,
+                     xy.data_ptr(), ids.data_ptr(), cnt.data_ptr(), center.data_ptr(),
+                     status.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               'cpe_detect_grid_bgr_batch_ex' if colour else 'cpe_detect_grid_batch_ex')
     return dict(xy=xy, id=ids, n=cnt, center=center, status=status, ws=ws, ws_generation=ws.generation)
 
 
@@ -136,22 +141,18 @@ def bgr_to_gray(bgr):
 
 
 def frames_to_device(images, device='cuda:0'):
-    """list of numpy u8 images of one size, each H x W (grey) or H x W x 3 (BGR as cv2.imread gives it) -> u8 tensor [n,h,w]
-    on the device.  3-channel frames go through the BGR2GRAY kernel (identity for a mono camera's replicated channels)."""
+    """list of numpy u8 images of one size, each H x W (grey) or H x W x 3 (BGR as cv2.imread gives it) -> u8 tensor on the
+    device: [n,h,w] if every image is grey, else [n,h,w,3] (grey images replicated into the three channels: the colour path
+    makes of a grey-replicated frame exactly what the grey path makes of the plane)."""
     arrs = [np.asarray(a) for a in images]
     for a in arrs:
         if a.dtype != np.uint8:
             raise TypeError('detect_grid expects uint8 images')
         if not (a.ndim == 2 or (a.ndim == 3 and a.shape[2] == 3)):
             raise ValueError(f'Unexpected input dimensions: {a.ndim}')        # util_cylinder.py:1788
-    out = torch.empty((len(arrs),) + arrs[0].shape[:2], dtype=torch.uint8, device=device)
-    col = [i for i, a in enumerate(arrs) if a.ndim == 3]
-    mono = [i for i, a in enumerate(arrs) if a.ndim == 2]
-    if mono:
-        out[mono] = torch.from_numpy(np.stack([arrs[i] for i in mono])).to(device)
-    if col:
-        out[col] = bgr_to_gray(torch.from_numpy(np.stack([np.ascontiguousarray(arrs[i]) for i in col])).to(device))
-    return out
+    if all(a.ndim == 2 for a in arrs):
+        return torch.from_numpy(np.stack(arrs)).to(device)
+    return torch.from_numpy(np.stack([np.ascontiguousarray(a) if a.ndim == 3 else np.repeat(a[..., None], 3, 2) for a in arrs])).to(device)
 
 
 def line_tables(det, frame, target='cylinder'):
@@ -186,7 +187,8 @@ def line_tables(det, frame, target='cylinder'):
 def draw_points(gray, xy):
     """the returned picture: BGR copy of the frame with the grid points marked (deterministic; the reference draws random
     colours, util_cylinder.py:1600-1601)"""
-    col_img = np.repeat(np.asarray(gray)[..., None], 3, axis=2)
+    g = np.asarray(gray)
+    col_img = g.copy() if g.ndim == 3 else np.repeat(g[..., None], 3, axis=2)
     for (x, y) in xy:
         xi, yi = int(x), int(y)
         col_img[max(yi - 2, 0):yi + 3, max(xi - 2, 0):xi + 3] = (0, 255, 0)

@@ -19,13 +19,14 @@ int ccl_run(const uint8_t *img, int n, int h, int w, int thr, int invert, int co
             uint8_t *touch, int count_mode, int *cnt, int use_rect, int *nrect, FrameState *st, hipStream_t s, int sparse = 0, int flags = 0, int cnt_sel = 0);
 int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t s);
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s,
-                 const RegionSide *side);
+                 const RegionSide *side, const uint8_t *lplane);
 int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s);
 int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s, int planar);
 int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuffers &B, FrameState *st, hipStream_t s);
 int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, FrameState *st, hipStream_t s,
                 const RegionSide *side, int planar, hipStream_t sj);
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
+int blur7_bgr(const uint8_t *bgr, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s);
 size_t lines_ws_bytes();
 int lines_stage(const int *lab_h, const int *lab_v, const uint8_t *exp_h, const uint8_t *exp_v, const uint8_t *g7, int n, int h, int w, const int *joints,
                 FrameState *st, void *lines_ws, double *o_xy, int *o_id, int *o_n, double *o_center, const uint8_t *gray,
@@ -44,7 +45,7 @@ struct Layout {
 enum Plane {
     P_BINARY = 0, P_HMASK, P_VMASK, P_MASK_CONTOUR, P_ROI_H, P_ROI_V, P_EXP_H, P_EXP_V, P_JOINTS, P_STATE, P_CL, P_G19, P_G7,
     P_JOINTS_MASK, P_TMPA, P_TMPB, P_CM, P_EXT, P_BASE_H, P_BASE_V, P_TOUCH, P_TMP16, P_LAB0, P_LAB1, P_ROOTS, P_JTMP,
-    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_HPAR, P_HTIME, P_GMID, P_FLJ, P_COUNT
+    P_VERTS, P_BEST, P_SEGS, P_HIST, P_LUT, P_BLOBS, P_BLOB_D, P_ORDER, P_DISTS, P_GROUPS, P_LOHI, P_HULL, P_LINES, P_NRECT, P_LAB2, P_LAB3, P_SW, P_SUBPIX, P_HL, P_BL, P_TL, P_BK, P_BITS, P_POOL, P_BLOB_CH, P_LABP, P_LABS, P_ROOTSP, P_ROOTSS, P_BEST2, P_HPAR, P_HTIME, P_GMID, P_FLJ, P_GRAYIN, P_COUNT
 };
 
 static_assert(P_COUNT <= 64, "Layout arrays too small");
@@ -228,9 +229,32 @@ extern "C" int32_t cpe_detect_grid_batch(const uint8_t *gray, int32_t n, int32_t
     return cpe_detect_grid_batch_ex(gray, n, h, w, nullptr, ws, ws_bytes, xy, id, n_pts, center, status, stream);
 }
 
-extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
-                                            void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
-                                            double *center, int32_t *status, void *stream)
+namespace cpe { namespace {
+// L channel of cv2.cvtColor(BGR2LAB) of a colour frame (util_cylinder.py:1840-1841), [ext] OpenCV 4.5.5 RGB2Lab_b: sRGB gamma
+// table per channel, Y row of sRGB -> XYZ (D65) in 12-bit fixed point, cube-root table folded into LY (tools/gen_lab_lut.py
+// colour).  R = G = B gives region.hip's c_lab_l.
+__constant__ uint16_t c_gamma[256] = { 0, 1, 1, 2, 2, 3, 4, 4, 5, 6, 6, 7, 8, 8, 9, 10, 11, 11, 12, 13, 14, 15, 16, 17, 19, 20, 21, 22, 24, 25, 26, 28, 29, 31, 33, 34, 36, 38, 40, 41, 43, 45, 47, 49, 51, 54, 56, 58, 60, 63, 65, 68, 70, 73, 75, 78, 81, 83, 86, 89, 92, 95, 98, 101, 105, 108, 111, 115, 118, 121, 125, 129, 132, 136, 140, 144, 147, 151, 155, 160, 164, 168, 172, 176, 181, 185, 190, 194, 199, 204, 209, 213, 218, 223, 228, 233, 239, 244, 249, 255, 260, 265, 271, 277, 282, 288, 294, 300, 306, 312, 318, 324, 331, 337, 343, 350, 356, 363, 370, 376, 383, 390, 397, 404, 411, 418, 426, 433, 440, 448, 455, 463, 471, 478, 486, 494, 502, 510, 518, 527, 535, 543, 552, 560, 569, 578, 586, 595, 604, 613, 622, 631, 641, 650, 659, 669, 678, 688, 698, 707, 717, 727, 737, 747, 757, 768, 778, 788, 799, 809, 820, 831, 842, 852, 863, 875, 886, 897, 908, 920, 931, 943, 954, 966, 978, 990, 1002, 1014, 1026, 1038, 1050, 1063, 1075, 1088, 1101, 1113, 1126, 1139, 1152, 1165, 1178, 1192, 1205, 1218, 1232, 1245, 1259, 1273, 1287, 1301, 1315, 1329, 1343, 1357, 1372, 1386, 1401, 1415, 1430, 1445, 1460, 1475, 1490, 1505, 1521, 1536, 1551, 1567, 1583, 1598, 1614, 1630, 1646, 1662, 1678, 1695, 1711, 1728, 1744, 1761, 1778, 1794, 1811, 1828, 1846, 1863, 1880, 1897, 1915, 1933, 1950, 1968, 1986, 2004, 2022, 2040 };
+__constant__ uint8_t c_ly[2041] = { 0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 27, 28, 29, 30, 31, 32, 33, 33, 34, 35, 36, 36, 37, 38, 38, 39, 40, 40, 41, 42, 42, 43, 43, 44, 45, 45, 46, 46, 47, 47, 48, 48, 49, 50, 50, 51, 51, 52, 52, 53, 53, 54, 54, 54, 55, 55, 56, 56, 57, 57, 58, 58, 58, 59, 59, 60, 60, 61, 61, 61, 62, 62, 63, 63, 63, 64, 64, 65, 65, 65, 66, 66, 66, 67, 67, 68, 68, 68, 69, 69, 69, 70, 70, 70, 71, 71, 71, 72, 72, 72, 73, 73, 73, 74, 74, 74, 75, 75, 75, 76, 76, 76, 77, 77, 77, 77, 78, 78, 78, 79, 79, 79, 80, 80, 80, 80, 81, 81, 81, 82, 82, 82, 82, 83, 83, 83, 83, 84, 84, 84, 85, 85, 85, 85, 86, 86, 86, 86, 87, 87, 87, 87, 88, 88, 88, 88, 89, 89, 89, 89, 90, 90, 90, 90, 91, 91, 91, 91, 92, 92, 92, 92, 93, 93, 93, 93, 94, 94, 94, 94, 95, 95, 95, 95, 95, 96, 96, 96, 96, 97, 97, 97, 97, 97, 98, 98, 98, 98, 99, 99, 99, 99, 99, 100, 100, 100, 100, 101, 101, 101, 101, 101, 102, 102, 102, 102, 102, 103, 103, 103, 103, 103, 104, 104, 104, 104, 104, 105, 105, 105, 105, 105, 106, 106, 106, 106, 106, 107, 107, 107, 107, 107, 108, 108, 108, 108, 108, 109, 109, 109, 109, 109, 109, 110, 110, 110, 110, 110, 111, 111, 111, 111, 111, 112, 112, 112, 112, 112, 112, 113, 113, 113, 113, 113, 114, 114, 114, 114, 114, 114, 115, 115, 115, 115, 115, 115, 116, 116, 116, 116, 116, 116, 117, 117, 117, 117, 117, 117, 118, 118, 118, 118, 118, 119, 119, 119, 119, 119, 119, 119, 120, 120, 120, 120, 120, 120, 121, 121, 121, 121, 121, 121, 122, 122, 122, 122, 122, 122, 123, 123, 123, 123, 123, 123, 124, 124, 124, 124, 124, 124, 124, 125, 125, 125, 125, 125, 125, 126, 126, 126, 126, 126, 126, 126, 127, 127, 127, 127, 127, 127, 128, 128, 128, 128, 128, 128, 128, 129, 129, 129, 129, 129, 129, 129, 130, 130, 130, 130, 130, 130, 130, 131, 131, 131, 131, 131, 131, 131, 132, 132, 132, 132, 132, 132, 132, 133, 133, 133, 133, 133, 133, 133, 134, 134, 134, 134, 134, 134, 134, 135, 135, 135, 135, 135, 135, 135, 135, 136, 136, 136, 136, 136, 136, 136, 137, 137, 137, 137, 137, 137, 137, 138, 138, 138, 138, 138, 138, 138, 138, 139, 139, 139, 139, 139, 139, 139, 139, 140, 140, 140, 140, 140, 140, 140, 141, 141, 141, 141, 141, 141, 141, 141, 142, 142, 142, 142, 142, 142, 142, 142, 143, 143, 143, 143, 143, 143, 143, 143, 144, 144, 144, 144, 144, 144, 144, 144, 145, 145, 145, 145, 145, 145, 145, 145, 146, 146, 146, 146, 146, 146, 146, 146, 147, 147, 147, 147, 147, 147, 147, 147, 147, 148, 148, 148, 148, 148, 148, 148, 148, 149, 149, 149, 149, 149, 149, 149, 149, 149, 150, 150, 150, 150, 150, 150, 150, 150, 151, 151, 151, 151, 151, 151, 151, 151, 151, 152, 152, 152, 152, 152, 152, 152, 152, 152, 153, 153, 153, 153, 153, 153, 153, 153, 154, 154, 154, 154, 154, 154, 154, 154, 154, 155, 155, 155, 155, 155, 155, 155, 155, 155, 156, 156, 156, 156, 156, 156, 156, 156, 156, 156, 157, 157, 157, 157, 157, 157, 157, 157, 157, 158, 158, 158, 158, 158, 158, 158, 158, 158, 159, 159, 159, 159, 159, 159, 159, 159, 159, 159, 160, 160, 160, 160, 160, 160, 160, 160, 160, 161, 161, 161, 161, 161, 161, 161, 161, 161, 161, 162, 162, 162, 162, 162, 162, 162, 162, 162, 163, 163, 163, 163, 163, 163, 163, 163, 163, 163, 164, 164, 164, 164, 164, 164, 164, 164, 164, 164, 165, 165, 165, 165, 165, 165, 165, 165, 165, 165, 166, 166, 166, 166, 166, 166, 166, 166, 166, 166, 167, 167, 167, 167, 167, 167, 167, 167, 167, 167, 168, 168, 168, 168, 168, 168, 168, 168, 168, 168, 168, 169, 169, 169, 169, 169, 169, 169, 169, 169, 169, 170, 170, 170, 170, 170, 170, 170, 170, 170, 170, 170, 171, 171, 171, 171, 171, 171, 171, 171, 171, 171, 172, 172, 172, 172, 172, 172, 172, 172, 172, 172, 172, 173, 173, 173, 173, 173, 173, 173, 173, 173, 173, 173, 174, 174, 174, 174, 174, 174, 174, 174, 174, 174, 174, 175, 175, 175, 175, 175, 175, 175, 175, 175, 175, 176, 176, 176, 176, 176, 176, 176, 176, 176, 176, 176, 176, 177, 177, 177, 177, 177, 177, 177, 177, 177, 177, 177, 178, 178, 178, 178, 178, 178, 178, 178, 178, 178, 178, 179, 179, 179, 179, 179, 179, 179, 179, 179, 179, 179, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 181, 181, 181, 181, 181, 181, 181, 181, 181, 181, 181, 181, 182, 182, 182, 182, 182, 182, 182, 182, 182, 182, 182, 183, 183, 183, 183, 183, 183, 183, 183, 183, 183, 183, 183, 184, 184, 184, 184, 184, 184, 184, 184, 184, 184, 184, 184, 185, 185, 185, 185, 185, 185, 185, 185, 185, 185, 185, 185, 186, 186, 186, 186, 186, 186, 186, 186, 186, 186, 186, 186, 187, 187, 187, 187, 187, 187, 187, 187, 187, 187, 187, 187, 187, 188, 188, 188, 188, 188, 188, 188, 188, 188, 188, 188, 188, 189, 189, 189, 189, 189, 189, 189, 189, 189, 189, 189, 189, 190, 190, 190, 190, 190, 190, 190, 190, 190, 190, 190, 190, 190, 191, 191, 191, 191, 191, 191, 191, 191, 191, 191, 191, 191, 191, 192, 192, 192, 192, 192, 192, 192, 192, 192, 192, 192, 192, 193, 193, 193, 193, 193, 193, 193, 193, 193, 193, 193, 193, 193, 194, 194, 194, 194, 194, 194, 194, 194, 194, 194, 194, 194, 194, 195, 195, 195, 195, 195, 195, 195, 195, 195, 195, 195, 195, 195, 196, 196, 196, 196, 196, 196, 196, 196, 196, 196, 196, 196, 196, 196, 197, 197, 197, 197, 197, 197, 197, 197, 197, 197, 197, 197, 197, 198, 198, 198, 198, 198, 198, 198, 198, 198, 198, 198, 198, 198, 199, 199, 199, 199, 199, 199, 199, 199, 199, 199, 199, 199, 199, 199, 200, 200, 200, 200, 200, 200, 200, 200, 200, 200, 200, 200, 200, 200, 201, 201, 201, 201, 201, 201, 201, 201, 201, 201, 201, 201, 201, 202, 202, 202, 202, 202, 202, 202, 202, 202, 202, 202, 202, 202, 202, 203, 203, 203, 203, 203, 203, 203, 203, 203, 203, 203, 203, 203, 203, 204, 204, 204, 204, 204, 204, 204, 204, 204, 204, 204, 204, 204, 204, 204, 205, 205, 205, 205, 205, 205, 205, 205, 205, 205, 205, 205, 205, 205, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 207, 207, 207, 207, 207, 207, 207, 207, 207, 207, 207, 207, 207, 207, 207, 208, 208, 208, 208, 208, 208, 208, 208, 208, 208, 208, 208, 208, 208, 209, 209, 209, 209, 209, 209, 209, 209, 209, 209, 209, 209, 209, 209, 209, 210, 210, 210, 210, 210, 210, 210, 210, 210, 210, 210, 210, 210, 210, 210, 211, 211, 211, 211, 211, 211, 211, 211, 211, 211, 211, 211, 211, 211, 211, 212, 212, 212, 212, 212, 212, 212, 212, 212, 212, 212, 212, 212, 212, 212, 213, 213, 213, 213, 213, 213, 213, 213, 213, 213, 213, 213, 213, 213, 213, 214, 214, 214, 214, 214, 214, 214, 214, 214, 214, 214, 214, 214, 214, 214, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 215, 216, 216, 216, 216, 216, 216, 216, 216, 216, 216, 216, 216, 216, 216, 216, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 217, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 218, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 219, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 220, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 221, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 222, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 223, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 224, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 225, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 226, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 227, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 228, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 229, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 230, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 231, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 232, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 233, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 234, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 235, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 236, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 237, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 238, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 239, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 240, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 241, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 242, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 243, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 244, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 245, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 246, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 247, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 248, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 249, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 250, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 251, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 252, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 253, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 254, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255 };
+__global__ __launch_bounds__(256) void k_bgr2labl(const uint8_t *__restrict__ bgr, size_t npx, uint8_t *__restrict__ L)
+{
+    __shared__ uint16_t s_g[256];
+    __shared__ uint8_t s_ly[2048];
+    s_g[threadIdx.x] = c_gamma[threadIdx.x];
+    for (int i = threadIdx.x; i < 2041; i += 256) s_ly[i] = c_ly[i];
+    __syncthreads();
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npx; p += (size_t)gridDim.x * 256) {
+        const int B = s_g[bgr[3 * p]], G = s_g[bgr[3 * p + 1]], R = s_g[bgr[3 * p + 2]];
+        L[p] = s_ly[(R * 871 + G * 2929 + B * 296 + (1 << 11)) >> 12];
+    }
+}
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ bgr, size_t npx, uint8_t *__restrict__ gray);
+} }
+
+// the call behind both entry points: grey frames (bgr == null) or true-colour frames (gray == null; the grey plane and the
+// L plane are made in the workspace first)
+static int32_t detect_impl(const uint8_t *gray, const uint8_t *bgr, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
+                           void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
+                           double *center, int32_t *status, void *stream)
 {
     CpeDetectParams prm = {0, 7, 1.0, CPE_TARGET_CYLINDER, 0};
     if (params) prm = *params;
@@ -239,7 +263,8 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     CPE_CHECK_ARG(prm.target == CPE_TARGET_CYLINDER || prm.target == CPE_TARGET_PLANE, "cpe_detect_grid_batch_ex: unknown target %d", prm.target);
     CPE_CHECK_ARG(!(prm.target == CPE_TARGET_PLANE && prm.subpixel), "cpe_detect_grid_batch_ex: no sub-pixel refinement for the planar target");
     const int planar = prm.target == CPE_TARGET_PLANE ? 1 : 0;
-    CPE_CHECK_ARG(gray && xy && id && n_pts && center && status, "cpe_detect_grid_batch: null pointer");
+    CPE_CHECK_ARG((gray || bgr) && xy && id && n_pts && center && status, "cpe_detect_grid_batch: null pointer");
+    CPE_CHECK_ARG(!(bgr && (planar || prm.subpixel)), "cpe_detect_grid_bgr_batch_ex: colour frames: cylinder target without sub-pixel refinement only");
     CPE_CHECK_ARG(n >= 0 && h >= 64 && w >= 64 && h <= 4096 && w <= 4096,
                   "cpe_detect_grid_batch: need n>=0 and 64 <= h,w <= 4096 (got %d,%d,%d)", n, h, w);
     if (n == 0) return CPE_OK;
@@ -253,6 +278,10 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     uint8_t *base = (uint8_t *)ws;
 #define PL(T, p) ((T *)(base + L.off[p]))
     FrameState *st = PL(FrameState, P_STATE);
+    // colour input: the grey plane lives in the workspace; the L plane borrows the disc plane of the region stage, which is
+    // first written (cleared) after CLAHE has read L
+    uint8_t *lplane = bgr ? PL(uint8_t, P_EXT) : nullptr;
+    if (bgr) gray = PL(uint8_t, P_GRAYIN);
     RegionBuffers R;
     R.cl = PL(uint8_t, P_CL); R.ext = PL(uint8_t, P_EXT); R.mc = PL(uint8_t, P_MASK_CONTOUR); R.touch = PL(uint8_t, P_TOUCH);
     R.lab = PL(int, P_LAB0); R.cnt = PL(int, P_LAB1); R.roots = PL(int, P_ROOTS); R.nrect = PL(int, P_NRECT); R.lab2 = PL(int, P_LAB2); R.cnt2 = PL(int, P_LAB3);
@@ -284,6 +313,12 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
         CPE_LAUNCH_BEGIN();
         CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
         CPE_CHECK_LAUNCH("k_state_init");
+        if (bgr) {      // BGR2GRAY (load_and_preprocess_image, mask_roi_around_center) and the L channel of BGR2LAB (detect_largest_blob)
+            const size_t npx = (size_t)n * h * w;
+            CPE_KLAUNCH(k_bgr2gray, dim3((unsigned)(((npx + 3) / 4 + 255) / 256)), dim3(256), 0, s, bgr, npx, PL(uint8_t, P_GRAYIN));
+            CPE_KLAUNCH(k_bgr2labl, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 1 << 16)), dim3(256), 0, s, bgr, npx, lplane);
+            CPE_CHECK_LAUNCH("colour planes");
+        }
         if (X.ok) {
             CPE_CHECK_HIP(hipEventRecord(X.fork, s));
             CPE_CHECK_HIP(hipStreamWaitEvent(X.s1, X.fork, 0));
@@ -296,7 +331,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
         if ((rc = spot_stage(gray, n, h, w, M, st, s2, planar)) != CPE_OK) return rc;
         RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d};
         if (planar) { if ((rc = region_stage_plane(gray, n, h, w, R, st, s)) != CPE_OK) return rc; }
-        else if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr)) != CPE_OK) return rc;
+        else if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr, lplane)) != CPE_OK) return rc;
         if (X.ok) {
             CPE_CHECK_HIP(hipEventRecord(X.join1, X.s1));
             CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
@@ -311,7 +346,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
             CPE_CHECK_HIP(hipEventRecord(X.fork, s));
             CPE_CHECK_HIP(hipStreamWaitEvent(X.s2, X.fork, 0));
             forked = true;
-            if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), X.s2)) != CPE_OK) return rc;
+            if ((rc = bgr ? blur7_bgr(bgr, n, h, w, st, PL(uint8_t, P_G7), X.s2) : blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), X.s2)) != CPE_OK) return rc;
         }
         if ((rc = masks_stage(gray, n, h, w, M, st, s, X.ok ? &rside : nullptr, planar, X.ok ? X.s2 : s)) != CPE_OK) return rc;   // joints: on s2 too
         if (X.ok) {
@@ -319,7 +354,7 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
             CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join2, 0));
             forked = false;
         }
-        else if ((rc = blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
+        else if ((rc = bgr ? blur7_bgr(bgr, n, h, w, st, PL(uint8_t, P_G7), s) : blur7_u8(gray, n, h, w, st, PL(uint8_t, P_G7), s)) != CPE_OK) return rc;
         if ((rc = lines_stage(PL(int, P_LAB0), PL(int, P_LAB1), M.exp_h, M.exp_v, PL(uint8_t, P_G7), n, h, w, M.joints, st, PL(void, P_LINES), xy, id,
                               n_pts, center, gray, prm.subpixel, prm.subpixel_window, prm.subpixel_step, PL(float, P_SUBPIX),
                               std::max(h, w) + 128, s, planar)) != CPE_OK)
@@ -341,6 +376,22 @@ extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int3
     }
     return rc;
 #undef PL
+}
+
+extern "C" int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
+                                            void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
+                                            double *center, int32_t *status, void *stream)
+{
+    CPE_CHECK_ARG(gray, "cpe_detect_grid_batch: null pointer");
+    return detect_impl(gray, nullptr, n, h, w, params, ws, ws_bytes, xy, id, n_pts, center, status, stream);
+}
+
+extern "C" int32_t cpe_detect_grid_bgr_batch_ex(const uint8_t *bgr, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
+                                                void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
+                                                double *center, int32_t *status, void *stream)
+{
+    CPE_CHECK_ARG(bgr && (((uintptr_t)bgr) & 3) == 0, "cpe_detect_grid_bgr_batch_ex: bgr must be a 4-byte aligned device pointer");
+    return detect_impl(nullptr, bgr, n, h, w, params, ws, ws_bytes, xy, id, n_pts, center, status, stream);
 }
 
 extern "C" int32_t cpe_detect_line_tables(const void *ws, size_t ws_bytes, int32_t n, int32_t h, int32_t w, int32_t frame,

@@ -1116,6 +1116,76 @@ inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
 
 
 // cv2.GaussianBlur(img,(7,7),0) for indexing_data (util_cylinder.py:1433)
+// indexing_data on a colour frame (util_cylinder.py:1433-1435): cv2.GaussianBlur(img, (7, 7), 0) channel by channel, then
+// cv2.cvtColor(BGR2GRAY) of the blurred image.  Same tiles and the same skip rule as the grey blur; bgr: u8[n,h,w,3].
+__global__ __launch_bounds__(256) void k_blur7_bgr(const uint8_t *__restrict__ bgr, int h, int w, int tiles_x, int tiles_y, Taps t,
+                                                   const FrameState *__restrict__ st, uint8_t *__restrict__ dst)
+{
+    constexpr int R = 3, IW = BT_X + 2 * R, IH = BT_Y + 2 * R, PER = BT_X * BT_Y / 256;
+    __shared__ uint8_t s_in[IH * IW];
+    __shared__ uint16_t s_h[IH * BT_X];
+    const int tid = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
+    const int gx0 = (tt % tiles_x) * BT_X, gy0 = (tt / tiles_x) * BT_Y;
+    const size_t N = (size_t)h * w;
+    const FrameState &S = st[f];
+    if (S.status != CPE_ST_OK) return;
+    int half = (int)(S.r0 / 5.0);
+    if (half < 3) half = 3;
+    if (half > 10) half = half + 5;
+    half = max(half, (int)(S.r0 / 4.5));
+    const int m = half + 1;
+    if (gx0 > S.rect[0] + S.rect[2] + m || gx0 + BT_X < S.rect[0] - m || gy0 > S.rect[1] + S.rect[3] + m || gy0 + BT_Y < S.rect[1] - m)
+        return;
+    const uint8_t *im = bgr + f * N * 3;
+    uint32_t ch[PER][3];
+    for (int c = 0; c < 3; c++) {
+        for (int i = tid; i < IH * IW; i += 256) {
+            int ry = i / IW, rx = i - ry * IW;
+            s_in[i] = im[((size_t)reflect101(gy0 - R + ry, h) * w + reflect101(gx0 - R + rx, w)) * 3 + c];
+        }
+        __syncthreads();
+        for (int i = tid; i < IH * BT_X; i += 256) {
+            int ry = i / BT_X, rx = i - ry * BT_X;
+            const uint8_t *p = &s_in[ry * IW + rx];
+            int sacc = 0;
+#pragma unroll
+            for (int j = 0; j <= 2 * R; j++) sacc += t.k[j] * p[j];
+            s_h[i] = (uint16_t)sacc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int i = tid + q * 256;
+            int ry = i / BT_X, rx = i - ry * BT_X;
+            const uint16_t *p = &s_h[ry * BT_X + rx];
+            int sacc = 0;
+#pragma unroll
+            for (int j = 0; j <= 2 * R; j++) sacc += t.k[j] * (int)p[j * BT_X];
+            ch[q][c] = (uint32_t)((sacc + (1 << (t.shift - 1))) >> t.shift);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int i = tid + q * 256;
+        int ry = i / BT_X, rx = i - ry * BT_X;
+        if (gy0 + ry < h && gx0 + rx < w)
+            dst[f * N + (size_t)(gy0 + ry) * w + gx0 + rx] = (uint8_t)((ch[q][0] * 3735u + ch[q][1] * 19235u + ch[q][2] * 9798u + 16384u) >> 15);
+    }
+}
+
+int blur7_bgr(const uint8_t *bgr, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s)
+{
+    Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};
+    CPE_LAUNCH_BEGIN();
+    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
+    CPE_KLAUNCH(k_blur7_bgr, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, bgr, h, w, tiles_x, tiles_y, t7, st, dst);
+    CPE_CHECK_LAUNCH("blur7_bgr");
+    return CPE_OK;
+}
+
 int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint8_t *dst, hipStream_t s)
 {
     Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};

@@ -28,8 +28,9 @@ __device__ __forceinline__ int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255
 // ---- CLAHE ----------------------------------------------------------------------------------------
 struct ClaheGeom { int tilesX, tilesY, tw, th, eh, ew, clipLimit; float lutScale; };
 
+// lab_lut != 0: `gray` is a grey frame and L = c_lab_l[grey]; 0: `gray` already is the L plane of a colour frame (k_bgr2labl)
 __global__ __launch_bounds__(256) void k_clahe_hist(const uint8_t *__restrict__ gray, int n, int h, int w, ClaheGeom g,
-                                                    int strips, unsigned int *__restrict__ hist)
+                                                    int strips, unsigned int *__restrict__ hist, int lab_lut)
 {
     __shared__ unsigned int sh[256];
     int b = blockIdx.x;
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void k_clahe_hist(const uint8_t *__restrict__ 
         int gy = reflect101(ty * g.th + yy, h);
         for (int xx = threadIdx.x; xx < g.tw; xx += 256) {
             int gx = reflect101(tx * g.tw + xx, w);
-            atomicAdd(&sh[c_lab_l[im[(size_t)gy * w + gx]]], 1u);
+            const int v = im[(size_t)gy * w + gx];
+            atomicAdd(&sh[lab_lut ? (int)c_lab_l[v] : v], 1u);
         }
     }
     __syncthreads();
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(unsigned int *__restrict__ hi
 constexpr int CLAHE_BLK_PX = 8192;
 __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ gray, int h, int w,
                                                      ClaheGeom g, const uint8_t *__restrict__ lut,
-                                                     uint8_t *__restrict__ dst, int *__restrict__ nrect)
+                                                     uint8_t *__restrict__ dst, int *__restrict__ nrect, int lab_lut)
 {
     __shared__ int s_b[4];
     __shared__ uint8_t s_lut[16 * 256];
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
         const uint32_t *src = reinterpret_cast<const uint32_t *>(lut + f * 16 * 256);   // tilesX = tilesY = 4
         uint32_t *d32 = reinterpret_cast<uint32_t *>(s_lut);
         for (int i = threadIdx.x; i < 16 * 256 / 4; i += 256) d32[i] = src[i];
-        s_lab[threadIdx.x] = c_lab_l[threadIdx.x];
+        s_lab[threadIdx.x] = lab_lut ? c_lab_l[threadIdx.x] : (uint8_t)threadIdx.x;
     }
     __syncthreads();
     int mnx = INT_MAX, mny = INT_MAX, mxx = -1, mxy = -1;
@@ -1665,9 +1667,12 @@ __global__ void k_region_reset(FrameState *st, int n, unsigned long long *best, 
 }  // namespace
 
 
+// lplane: L channel of BGR2LAB of a colour frame (util_cylinder.py:1840 on a 3-channel image), or null: grey frames, L = LUT[grey]
 int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const RegionBuffers &B, FrameState *st, hipStream_t s,
-                 const RegionSide *side)
+                 const RegionSide *side, const uint8_t *lplane)
 {
+    const int lab_lut = lplane ? 0 : 1;
+    if (lplane) gray = lplane;
     const size_t N = (size_t)h * w, total = N * n;
     ClaheGeom g;
     g.tilesX = 4; g.tilesY = 4;
@@ -1682,9 +1687,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best, B.nrect);
     (void)hipMemsetAsync(B.hist, 0, (size_t)n * 16 * 256 * sizeof(unsigned int), s);
     const int strips = 8;
-    CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist);
+    CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist, lab_lut);
     CPE_KLAUNCH(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
-    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + CLAHE_BLK_PX - 1) / CLAHE_BLK_PX), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect);
+    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + CLAHE_BLK_PX - 1) / CLAHE_BLK_PX), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect, lab_lut);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
     if (side) {   // the 17 one-bit planes only need the CLAHE image

@@ -45,21 +45,15 @@ def write_image(path, bgr):
 
 
 def undistort_group(images, und):
-    """list of same-size numpy images of one camera -> u8 tensor [n,h,w] of undistorted grey frames on the device.
-    Colour frames are remapped plane by plane and only then converted (cv2.undistort works per channel and
-    load_and_preprocess_image's BGR2GRAY comes after it)."""
+    """list of same-size numpy images of one camera -> undistorted frames on the device: u8 [n,h,w] if all are grey, else
+    [n,h,w,3] BGR (grey ones replicated).  cv2.undistort works per channel; the conversions of detect_grid come after it."""
     dev = und.device
-    out = torch.empty((len(images), und.h, und.w), dtype=torch.uint8, device=dev)
-    mono = [i for i, a in enumerate(images) if a.ndim == 2]
-    col = [i for i, a in enumerate(images) if a.ndim == 3]
-    if mono:
-        out[mono] = und(torch.from_numpy(np.stack([images[i] for i in mono])).to(dev))
-    if col:
-        planes = torch.from_numpy(np.stack([np.moveaxis(images[i], 2, 0) for i in col])).to(dev)      # [m,3,h,w]
-        m = planes.shape[0]
-        flat = und(planes.reshape(m * 3, und.h, und.w).contiguous()).reshape(m, 3, und.h, und.w)
-        out[col] = api.bgr_to_gray(flat.permute(0, 2, 3, 1).contiguous())
-    return out
+    if all(a.ndim == 2 for a in images):
+        return und(torch.from_numpy(np.stack(images)).to(dev))
+    planes = torch.from_numpy(np.stack([np.moveaxis(a, 2, 0) if a.ndim == 3 else np.repeat(a[None], 3, 0) for a in images])).to(dev)   # [n,3,h,w]
+    m = planes.shape[0]
+    flat = und(planes.reshape(m * 3, und.h, und.w).contiguous()).reshape(m, 3, und.h, und.w)
+    return flat.permute(0, 2, 3, 1).contiguous()
 
 
 def run_folder(json_path, folder_path, output_folder=None, target='cylinder', chunk=32, device='cuda:0'):

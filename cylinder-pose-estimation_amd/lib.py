@@ -34,6 +34,8 @@ _SIGS = {
                               [C.c_void_p] * 6),
     'cpe_detect_grid_batch_ex': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t] +
                                  [C.c_void_p] * 6),
+    'cpe_detect_grid_bgr_batch_ex': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t] +
+                                     [C.c_void_p] * 6),
     'cpe_detect_line_tables': (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     'cpe_bgr2gray_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_detect_workspace_plane': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -134,12 +134,18 @@ CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t
 CPE_API int32_t cpe_detect_line_tables(const void *ws, size_t ws_bytes, int32_t n, int32_t h, int32_t w, int32_t frame,
                                        double *eq, int32_t *npts, double *pts, int32_t *n_lines, void *stream);
 
-/* Colour input of the entry point: load_and_preprocess_image converts a 3-channel frame with
- * cv2.cvtColor(BGR2GRAY) (util_cylinder.py:1781-1789): 8-bit fixed point, gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
- * ([ext] OpenCV 4.5.5; identity on grey-replicated frames).  bgr u8[n,h,w,3] interleaved -> gray u8[n,h,w]; both
- * 4-byte aligned device buffers.  The detector then runs on `gray`; the two places where the reference looks at the
- * colour planes again (LAB L channel of the blob stage, :1840; the 7x7 blur of indexing_data, :1433) see the grey-
- * replicated image here, which is what a mono laser camera delivers. */
+/* Colour input.  The reference's CLI hands detect_grid the H x W x 3 BGR array of cv2.imread (python_grid_detection_cylinder.py:34-44);
+ * load_and_preprocess_image (util_cylinder.py:1781-1789) and mask_roi_around_center (:1957) work on cv2.cvtColor(BGR2GRAY) of it:
+ * 8-bit fixed point, gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15 ([ext] OpenCV 4.5.5; identity on grey-replicated frames);
+ * detect_largest_blob takes the L channel of cv2.cvtColor(BGR2LAB) of the COLOUR image (:1840) and indexing_data blurs the colour
+ * image 7x7 channel by channel before converting it (:1433-1435).
+ *   cpe_bgr2gray_batch             bgr u8[n,h,w,3] interleaved -> gray u8[n,h,w]; both 4-byte aligned device buffers.
+ *   cpe_detect_grid_bgr_batch_ex   the whole of detect_grid on true-colour frames: same outputs, workspace and status codes as
+ *                                  cpe_detect_grid_batch_ex (cylinder target, no sub-pixel refinement); on grey-replicated
+ *                                  frames it returns what cpe_detect_grid_batch returns for the grey plane. */
+CPE_API int32_t cpe_detect_grid_bgr_batch_ex(const uint8_t *bgr, int32_t n, int32_t h, int32_t w, const CpeDetectParams *params,
+                                             void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
+                                             double *center, int32_t *status, void *stream);
 CPE_API int32_t cpe_bgr2gray_batch(const uint8_t *bgr, int32_t n, int32_t h, int32_t w, uint8_t *gray, void *stream);
 
 /* Where an intermediate of the last cpe_detect_grid_batch call lives inside the workspace (for

@@ -53,9 +53,37 @@ ORC_API int orc_detect_grid(const uint8_t *gray, int h, int w, double *center, d
     return orc_detect_grid_ex(gray, h, w, 0, 7, 1.0, center, xy, id, cap, n_out, dbg);
 }
 
+static int detect_grid_impl(const uint8_t *gray, const uint8_t *bgr, int h, int w, int subpixel, int sp_window, double sp_step, double *center,
+                            double *xy, int *id, int cap, int *n_out, orc_detect_debug *dbg);
+
 /* subpixel != 0: modify_grayscale_Cline between remove_label and the intersections (the call commented out at :2040) */
 ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, int sp_window, double sp_step, double *center,
                                double *xy, int *id, int cap, int *n_out, orc_detect_debug *dbg)
+{
+    return detect_grid_impl(gray, NULL, h, w, subpixel, sp_window, sp_step, center, xy, id, cap, n_out, dbg);
+}
+
+void orc_bgr2gray(const uint8_t *bgr, size_t npx, uint8_t *gray);
+void orc_lab_l_bgr(const uint8_t *bgr, int h, int w, uint8_t *L);
+int orc_detect_largest_blob_l(const uint8_t *gray, const uint8_t *l_in, int h, int w, double clip, uint8_t *mask, int *rect,
+                              uint8_t *cl_out, int *nkp_out);
+
+/* detect_grid on a true-colour frame (H x W x 3 BGR, the CLI's cv2.imread): load_and_preprocess_image and
+ * mask_roi_around_center work on BGR2GRAY of it (util_cylinder.py:1781-1789, :1957); detect_largest_blob takes the L channel
+ * of BGR2LAB of the COLOUR image (:1840); indexing_data blurs the colour image 7x7 channel by channel and converts the
+ * result to grey (:1433-1435). */
+ORC_API int orc_detect_grid_bgr(const uint8_t *bgr, int h, int w, double *center, double *xy, int *id, int cap, int *n_out,
+                                orc_detect_debug *dbg)
+{
+    uint8_t *gray = (uint8_t *)malloc((size_t)h * w);
+    orc_bgr2gray(bgr, (size_t)h * w, gray);
+    const int st = detect_grid_impl(gray, bgr, h, w, 0, 7, 1.0, center, xy, id, cap, n_out, dbg);
+    free(gray);
+    return st;
+}
+
+static int detect_grid_impl(const uint8_t *gray, const uint8_t *bgr, int h, int w, int subpixel, int sp_window, double sp_step, double *center,
+                            double *xy, int *id, int cap, int *n_out, orc_detect_debug *dbg)
 {
     size_t N = (size_t)h * w;
     uint8_t *blurred = (uint8_t *)malloc(N), *binary = (uint8_t *)malloc(N);
@@ -75,7 +103,10 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
     /* 2 */ int nj = orc_extract_joints(binary, h, w, hmask, vmask, cent, capj);
     if (nj > capj) nj = capj;
     int rect[4] = {0, 0, 0, 0}, r0 = 0, spot[4] = {0, 0, 0, 0}, nkp = 0;
-    /* 3 */ st = orc_detect_largest_blob(gray, h, w, 4.5, mc, rect, NULL, &nkp);
+    uint8_t *lplane = NULL;
+    if (bgr) { lplane = (uint8_t *)malloc(N); orc_lab_l_bgr(bgr, h, w, lplane); }
+    /* 3 */ st = orc_detect_largest_blob_l(gray, lplane, h, w, 4.5, mc, rect, NULL, &nkp);
+    free(lplane);
     int ncyl = 0;
     if (st == 0) {
         /* 4: keep joints inside boundingRect(max_contour) (half-open, :1918) */
@@ -113,7 +144,16 @@ ORC_API int orc_detect_grid_ex(const uint8_t *gray, int h, int w, int subpixel, 
         if (st == 0) {
             orc_intersections(rows, cols, rect);
             orc_clean_and_relabel(rows, cols);
-            orc_blur7(gray, h, w, g7);
+            if (bgr) {      /* :1433-1435: GaussianBlur((7,7)) of the colour image, channel by channel, then BGR2GRAY */
+                uint8_t *pl = (uint8_t *)malloc(N), *bl = (uint8_t *)malloc(3 * N);
+                for (int c = 0; c < 3; c++) {
+                    for (size_t i = 0; i < N; i++) pl[i] = bgr[3 * i + c];
+                    orc_blur7(pl, h, w, g7);
+                    for (size_t i = 0; i < N; i++) bl[3 * i + c] = g7[i];
+                }
+                orc_bgr2gray(bl, N, g7);
+                free(pl); free(bl);
+            } else orc_blur7(gray, h, w, g7);
             int n = orc_index_points(rows, cols, g7, h, w, r0, center, xy, id, cap);
             if (n < 0) st = -n;
             else if (n > CPE_MAXP) orc_capacity_overflow = 1;   /* more grid points than a table of the boundary holds */

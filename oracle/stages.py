@@ -275,6 +275,23 @@ def detect_grid(gray, cap=4096, debug=False, subpixel=False, window=7, step=1.0,
     return out
 
 
+def detect_grid_bgr(bgr, cap=4096):
+    """detect_grid on a true-colour frame H x W x 3 (BGR): the blob stage sees the L channel of BGR2LAB of the colour image,
+    indexing_data the 7x7 blur of the colour image converted to grey (util_cylinder.py:1840, :1433-1435)"""
+    bgr = np.ascontiguousarray(bgr, np.uint8); h, w, _ = bgr.shape
+    center = np.zeros(2); xy = np.zeros((cap, 2)); ids = np.zeros((cap, 2), np.int32); n = C.c_int(0)
+    dbg = DetectDebug()
+    st = lib().orc_detect_grid_bgr(_p(bgr, C.c_uint8), h, w, _p(center, C.c_double), _p(xy, C.c_double), _p(ids, C.c_int), cap,
+                                   C.byref(n), C.byref(dbg))
+    return dict(status=st, center=center, xy=xy[:n.value].copy(), id=ids[:n.value].copy(), rect=tuple(dbg.rect), r0=dbg.r0,
+                n_keypoints=dbg.n_keypoints)
+
+
+def lab_l_bgr(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8); h, w, _ = bgr.shape; out = np.zeros((h, w), np.uint8)
+    lib().orc_lab_l_bgr(_p(bgr, C.c_uint8), h, w, _p(out, C.c_uint8)); return out
+
+
 def lineset_from_equations(eqs):
     """LineSet carrying only equations (for the sub-pixel refinement tests)"""
     ls = LineSet(); ls.nlines = len(eqs)

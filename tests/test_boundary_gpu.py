@@ -55,10 +55,9 @@ def test_cylinder_entry_module_folder(cpe, orc, gpu, tmp_path):
             if cam == 'L' and i == 1:
                 bgr = np.stack([np.minimum(255, img.astype(np.int32) + 3).astype(np.uint8), img, (img * 0.9).astype(np.uint8)], 2)
                 und = np.stack([oracle.undistort(np.ascontiguousarray(bgr[..., c]), np.array(K), dist) for c in range(3)], 2)
-                gray = S.bgr2gray(und)
+                ref = S.detect_grid_bgr(und)                # a colour file takes the colour path (LAB L, per-channel 7x7 blur)
             else:
-                gray = oracle.undistort(img, np.array(K), dist)
-            ref = S.detect_grid(gray)
+                ref = S.detect_grid(oracle.undistort(img, np.array(K), dist))
             got = res[f'{nm}{cam}']
             assert ref['status'] == 0
             assert [p['id'] for p in got['points']] == ref['id'].tolist(), (nm, cam)
@@ -99,8 +98,8 @@ def test_line_tables_refuse_a_workspace_that_has_moved_on(cpe, orc, gpu):
 
 @pytest.mark.gpu
 def test_colour_input_and_error_behaviour(cpe, orc, gpu):
-    """BGR2GRAY kernel == oracle on random colour data (incl. a ragged tail); detect_grid on a colour frame == detect_grid
-    on its luma; the drop-in detect_grid never raises (reference :111-112)."""
+    """BGR2GRAY kernel == oracle on random colour data (incl. a ragged tail); detect_grid on a colour frame == the oracle's
+    colour path; the drop-in detect_grid never raises (reference :111-112)."""
     import importlib
     from oracle import stages as S
     rng = np.random.default_rng(5)
@@ -115,7 +114,7 @@ def test_colour_input_and_error_behaviour(cpe, orc, gpu):
     tint = np.stack([np.minimum(255, f.astype(np.int32) + 4).astype(np.uint8), f, (f * 0.93).astype(np.uint8)], 2)
     mod = importlib.import_module('python_grid_detection_cylinder')
     out = mod.detect_grid(tint)
-    ref = S.detect_grid(S.bgr2gray(tint))
+    ref = S.detect_grid_bgr(tint)
     assert out is not None and ref['status'] == 0
     d = json.loads(out[1])
     assert [p['id'] for p in d['points']] == ref['id'].tolist()
@@ -123,6 +122,44 @@ def test_colour_input_and_error_behaviour(cpe, orc, gpu):
     assert mod.detect_grid(np.zeros((480, 640), np.float32)) is None          # wrong dtype: printed, not raised
     assert mod.detect_grid(np.zeros((4, 480, 640, 3), np.uint8)) is None      # wrong rank
     assert mod.detect_grid(np.zeros((16, 16), np.uint8)) is None              # C-ABI argument error (CpeError) is caught too
+
+
+@pytest.mark.gpu
+def test_true_colour_frames(cpe, orc, gpu):
+    """a colour camera's view of a red laser grid (R strong, G and B weak, channels with their own noise): the two places
+    where the reference looks at the colour planes again -- the L channel of BGR2LAB in detect_largest_blob
+    (util_cylinder.py:1840) and the per-channel 7x7 blur of indexing_data (:1433-1435) -- are what the colour entry point
+    computes: CLAHE plane, status, centre and every point equal the oracle's colour path; and the colour path is not the
+    luma path in disguise (the L plane differs from L of the luma on a large share of the pixels)."""
+    from oracle import stages as S
+    rng = np.random.default_rng(12)
+    f = _frames(480, 640, 2, 3)
+    frames = []
+    for g in (f['left'][0].numpy(), f['right'][1].numpy()):
+        r = g.astype(np.int32)
+        bgr = np.stack([r * 0.18 + rng.integers(0, 6, g.shape), r * 0.35 + rng.integers(0, 6, g.shape), r + rng.integers(-2, 3, g.shape)], 2)
+        bgr[g >= 245] = g[g >= 245][:, None]                  # the saturated spot blooms white on every channel
+        frames.append(np.clip(bgr, 0, 255).astype(np.uint8))
+    frames = np.stack(frames)
+    det = cpe.api.detect_grid_batch(torch.from_numpy(frames).to(gpu))
+    torch.cuda.synchronize()
+    clahe = det['ws'].plane('clahe').cpu().numpy()
+    for i in range(2):
+        ref = S.detect_grid_bgr(frames[i])
+        L = S.lab_l_bgr(frames[i])
+        assert (L != S.lab_l(S.bgr2gray(frames[i]))).mean() > 0.2
+        assert np.array_equal(clahe[i], S.clahe(L))
+        assert int(det['status'][i]) == ref['status'] == 0
+        m = int(det['n'][i])
+        assert m == len(ref['xy']) and m > 20
+        assert np.array_equal(det['id'][i, :m].cpu().numpy(), ref['id'])
+        assert np.array_equal(det['xy'][i, :m].cpu().numpy(), ref['xy'])
+        assert np.array_equal(det['center'][i].cpu().numpy(), ref['center'])
+    # grey-replicated colour frames: exactly the grey path
+    g = f['left'][1].numpy()
+    a = cpe.api.detect_grid_batch(torch.from_numpy(np.repeat(g[None, ..., None], 3, 3)).to(gpu))
+    b = cpe.api.detect_grid_batch(torch.from_numpy(g[None]).to(gpu))
+    assert int(a['status'][0]) == int(b['status'][0]) == 0 and torch.equal(a['xy'], b['xy']) and torch.equal(a['id'], b['id'])
 
 
 @pytest.mark.gpu

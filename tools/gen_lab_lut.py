@@ -26,3 +26,14 @@ for v in range(256):
     L = (Lscale * fY + Lshift + (1 << (lab_shift2 - 1))) >> lab_shift2
     lut.append(min(255, max(0, L)))
 print(', '.join(map(str, lut)))
+# true-colour input: L = LY[(gam[R] * 871 + gam[G] * 2929 + gam[B] * 296 + 2048) >> 12]   (Y row of sRGB -> XYZ (D65) in 12-bit
+# fixed point: cvRound(4096 * {0.212671, 0.715160, 0.072169}), sum 4096, so R = G = B = v gives Y = gam[v] and L = lut[v])
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == 'colour':
+    LY = []
+    for y in range(255 * (1 << gamma_shift) + 1):
+        L = (Lscale * cb[y] + Lshift + (1 << (lab_shift2 - 1))) >> lab_shift2
+        LY.append(min(255, max(0, L)))
+    assert all(LY[gam[v]] == lut[v] for v in range(256))
+    print('GAMMA[256] =', ', '.join(map(str, gam)))
+    print(f'LY[{len(LY)}] =', ', '.join(map(str, LY)))
