@@ -41,3 +41,15 @@ with open(out + '/pmc_sq_summary.csv', 'w') as f:
 print(open(out + '/pmc_sq_summary.csv').read()[:3000])
 PY
 head -30 "$OUT/occupancy_overlap.txt"
+# HBM traffic per kernel: separate FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh form) around tools/time_detect.py 32 (64 images per launch)
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  CPE_SERIAL=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_hbm/$c" -o pmc -- python3 "$GRAFT_REPO_ROOT/tools/time_detect.py" 32 > "$OUT/pmc_hbm_$c.log" 2>&1
+  echo "rocprofv3 $c exit $?" >> "$OUT/pmc_hbm_$c.log"
+done
+cd "$GRAFT_REPO_ROOT"
+python3 tools/pmc_summary.py "$OUT/pmc_hbm" 64 > "$OUT/pmc_summary.csv" 2>&1
+head -12 "$OUT/pmc_summary.csv"
+# keep the summaries, drop the bulk (gpurun only copies back 64 MiB)
+find "$OUT" \( -name '*kernel_trace.csv' -o -name '*counter_collection.csv' -o -name '*.db' -o -name '*agent_info.csv' \) -delete
+du -sh "$OUT"
