@@ -338,7 +338,7 @@ def run_rank(args):
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
     auto_chunk = args.chunk <= 0
     if auto_chunk:
-        args.chunk = 176 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~280 MB (1920x1200) / ~765 MB (4K) of workspace
+        args.chunk = 228 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~197 MB (1920x1200) / ~637 MB (4K) of workspace
     if scaling == 'strong':
         total = args.frames
         lo, hi = D.shard_range(total, rank, world)
@@ -347,9 +347,11 @@ def run_rank(args):
         lo, hi = rank * args.frames, (rank + 1) * args.frames
     F = hi - lo
     if auto_chunk and F > 0:
-        # equal chunks of at most 176 frames (measured: 160-180 frames per call is the sweet spot whatever the number of
-        # lanes -- 512 frames as 3 x 171: 2414 frames/s, as 4 x 128: 2247, as 2 x 256: 2317; an odd number of chunks on two
-        # lanes costs nothing); a shard that fits one call of 256 frames is not split
+        # equal chunks of at most 228 frames (round 3, workspace 195 MB per image: 208-240 frames per call is the sweet spot --
+        # 4096 frames as chunks of 171: 2767 frames/s, 208: 2854, 224: 2867, 240: 2865, 300: 2753; calls of exactly 256 or 512
+        # images are 6-10 % slower than their neighbours (128: 2478, 256: 2712) -- not an alignment effect: skewing the plane
+        # offsets and the lanes' workspaces changed nothing; an odd number of chunks on two lanes costs nothing);
+        # a shard that fits one call of 256 frames is not split
         nch = 1 if F <= 256 and H * W <= 1920 * 1200 else -(-F // args.chunk)
         args.chunk = -(-F // nch)
     # ---- synthetic inputs, resident in HBM before the timed region
@@ -498,8 +500,8 @@ def main():
     ap.add_argument('--scaling', choices=['strong', 'weak'], default=None,
                     help='default: strong for N > 1 (BASELINE.json configs[3]: the 4096-frame batch sharded N x)')
     ap.add_argument('--chunk', type=int, default=0,
-                    help='stereo frames per kernel batch (workspace size); 0 = equal chunks of at most 176 frames at 1920x1200 '
-                         '(171 for a 4096-frame shard), 56 at 3840x2160 (x --lanes in flight)')
+                    help='stereo frames per kernel batch (workspace size); 0 = equal chunks of at most 228 frames at 1920x1200 '
+                         '(228 for a 4096-frame shard, 171 for a 512-frame one), 56 at 3840x2160 (x --lanes in flight)')
     ap.add_argument('--lanes', type=int, default=2,
                     help='chunks in flight, each on its own HIP stream with its own workspace: the narrow tail of one chunk (fragments, '
                          'lines: one workgroup per image) runs beside the wide kernels of the next')

@@ -644,7 +644,7 @@ int ccl_ctl(FrameState *st, int *nrect, int n, int h, int w, int op, hipStream_t
 // found earlier (icvFindNextContour: the last border mark passed on the row is positive), i.e. every component that sits
 // in a hole of another one, at any depth.  Equivalent, scan-free form: a component is external iff the background pixel
 // west of its raster-first pixel belongs to the OUTER background, the 4-connected background region that reaches the
-// border of the window.  This kernel computes that region as a bit mask, one wavefront per frame:
+// border of the window.  This kernel computes that region as a bit mask, one workgroup per frame:
 //   out[y][j] bit b = 1  <=>  pixel (64 j + b, y) is background and 4-connected to the window border through background
 // by alternating downward / upward sweeps over the rows (lane j owns word j of a row; a row takes what the previous row
 // of the sweep has, fills it sideways through runs of background -- carry-ripple fill inside a word, lane exchange across
@@ -690,50 +690,75 @@ __device__ __forceinline__ unsigned long long flood_row(unsigned long long bg, u
     return f;
 }
 
-__global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict__ mask, int h, int w, FrameState *__restrict__ st,
-                                                      int use_rect, unsigned long long *__restrict__ bgw_all,
-                                                      unsigned long long *__restrict__ out_all, size_t plane_words)
+// One workgroup per frame, FLOOD_BANDS wavefronts: the window's rows are cut into bands, one per wavefront.  A round is a
+// downward and an upward sweep of every band at the same time, each starting from what its neighbour band's boundary row held
+// at the last barrier (rows outside the window: all outer background); rounds repeat until one changes nothing anywhere.
+// The result is the least fixed point of "background next to outer background (or to the window border) is outer
+// background", which does not depend on the order of the updates: the same mask as one wavefront sweeping the whole window
+// (the round-2 form: 1.16 ms per launch at 1920x1200, a serial walk of ~1000 rows three times).  The left / right window
+// columns seed every row directly, so a sparse mask is nearly done after the first sweep of each band whatever the band above
+// knows; what is shadowed from both sides on its own row gets filled from the rows above / below in the next rounds.
+constexpr int FLOOD_BANDS = 16;
+__global__ __launch_bounds__(64 * FLOOD_BANDS) void k_outside_flood(const uint8_t *__restrict__ mask, int h, int w, FrameState *__restrict__ st,
+                                                                   int use_rect, unsigned long long *__restrict__ bgw_all,
+                                                                   unsigned long long *__restrict__ out_all, size_t plane_words,
+                                                                   const uint32_t *__restrict__ bits)
 {
+    // bits (optional): the mask's one-bit plane (build_bitplanes, 1 plane per frame) -- an eighth of the bytes of the first sweep
+    __shared__ int s_any[2];
     const size_t f = blockIdx.x;
-    const int lane = threadIdx.x, WW = (w + 63) >> 6;
+    const int lane = threadIdx.x & 63, band = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), WW = (w + 63) >> 6;
     const Rect r = get_rect(st, f, use_rect, h, w);
     if (r.x1 < r.x0 || r.y1 < r.y0) return;
     const uint8_t *im = mask + f * (size_t)h * w;
+    const int bws = bit_row_words(w);
+    const uint32_t *bp = bits ? bits + f * (size_t)h * bws : nullptr;
     unsigned long long *bgw = bgw_all + f * plane_words, *out = out_all + f * plane_words;
     const int x0 = lane * 64;
     const unsigned long long cmask = lane < WW ? col_mask64(x0, r.x0, r.x1) : 0ull;
-    // window columns x0r / x1r touch the outside on their left / right
+    // window columns r.x0 / r.x1 touch the outside on their left / right
     unsigned long long edge = 0;
     if (lane < WW) {
         if (r.x0 >= x0 && r.x0 < x0 + 64) edge |= 1ull << (r.x0 - x0);
         if (r.x1 >= x0 && r.x1 < x0 + 64) edge |= 1ull << (r.x1 - x0);
     }
-    // Rows are loaded ahead of their use: the flood of a row only needs the previous row's result (a register), so the
-    // next chunk of rows is requested before the current one is worked on and the memory round trip -- what a
-    // row-at-a-time loop spends nearly all its time on -- overlaps the arithmetic.
-    constexpr int CHUNK = 8;
     const int nrows = r.y1 - r.y0 + 1;
-    // sweep 0 (down): pack the background once, seed from the window border
-    unsigned long long prev = ~0ull;   // the row above the window is all outside
+    const int per = (nrows + FLOOD_BANDS - 1) / FLOOD_BANDS;
+    const int ya = r.y0 + band * per, yb = min(r.y1, ya + per - 1);      // this wavefront's rows (none: yb < ya)
+    const int mine = max(0, yb - ya + 1);
+    if (threadIdx.x < 2) s_any[threadIdx.x] = 0;
+    // Rows are loaded ahead of their use: the flood of a row only needs the previous row's result (a register), so the
+    // next chunk of rows is requested before the current one is worked on.
+    constexpr int CHUNK = 8;
+    // boundary row of the neighbour band as of the last barrier (L1-bypassing load: another wavefront wrote it)
+    auto nb_row = [&](int y) -> unsigned long long {
+        if (y < r.y0 || y > r.y1) return ~0ull;                         // outside the window: all outer background
+        return lane < WW ? __hip_atomic_load(&out[(size_t)y * WW + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    };
+    // ---- first sweep (down): pack the background once, seed from the window border; the band above is not known yet
     {
+        unsigned long long prev = band == 0 ? ~0ull : 0ull;
         unsigned long long nxt[CHUNK];
         auto load0 = [&](int k0, unsigned long long *dst) {
 #pragma unroll
             for (int k = 0; k < CHUNK; k++) {
-                const int y = r.y0 + k0 + k;
-                dst[k] = (lane < WW && k0 + k < nrows) ? (~pack_nonzero64(im + (size_t)y * w, x0, w) & cmask) : 0ull;
+                const int y = ya + k0 + k;
+                unsigned long long m = 0;
+                if (lane < WW && k0 + k < mine)    // pixel x is bit x + 32 of its plane row: pixels 64 j .. 64 j + 63 are words 1 + 2 j, 2 + 2 j
+                    m = bp ? *reinterpret_cast<const u64_a4 *>(bp + (size_t)y * bws + 1 + 2 * lane) : pack_nonzero64(im + (size_t)y * w, x0, w);
+                dst[k] = ~m & cmask;
             }
         };
         load0(0, nxt);
-        for (int k0 = 0; k0 < nrows; k0 += CHUNK) {
+        for (int k0 = 0; k0 < mine; k0 += CHUNK) {
             unsigned long long bgc[CHUNK];
 #pragma unroll
             for (int k = 0; k < CHUNK; k++) bgc[k] = nxt[k];
-            if (k0 + CHUNK < nrows) load0(k0 + CHUNK, nxt);
+            if (k0 + CHUNK < mine) load0(k0 + CHUNK, nxt);
 #pragma unroll
             for (int k = 0; k < CHUNK; k++) {
-                if (k0 + k >= nrows) break;
-                const int y = r.y0 + k0 + k;
+                if (k0 + k >= mine) break;
+                const int y = ya + k0 + k;
                 const unsigned long long bg = bgc[k];
                 unsigned long long seed = (prev | edge) & bg;
                 if (y == r.y1) seed = bg;      // the row below the window is all outside
@@ -744,35 +769,36 @@ __global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict_
             }
         }
     }
-    // further sweeps, alternating direction, until nothing changes (this wavefront's own stores: visible to it in order;
-    // a row's entry is only rewritten by the step that works on that row, so loading it a chunk early is safe)
+    __syncthreads();
+    // ---- further sweeps (up, down, up, ...) until a whole round changes nothing in any band.  A row's entry is only
+    // rewritten by the wavefront that owns it, in program order, so loading it a chunk early is safe.
     bool converged = false;
     for (int pass = 1; pass < FLOOD_MAX_PASSES; pass++) {
         const bool upw = pass & 1;
         bool any = false;
-        prev = ~0ull;
+        unsigned long long prev = mine > 0 ? nb_row(upw ? yb + 1 : ya - 1) : 0ull;
         unsigned long long nb[CHUNK], nc[CHUNK];
         auto load1 = [&](int k0, unsigned long long *db, unsigned long long *dc) {
 #pragma unroll
             for (int k = 0; k < CHUNK; k++) {
                 const int kk = k0 + k;
-                const int y = upw ? r.y1 - kk : r.y0 + kk;
-                const bool ok = lane < WW && kk < nrows;
+                const int y = upw ? yb - kk : ya + kk;
+                const bool ok = lane < WW && kk < mine;
                 db[k] = ok ? bgw[(size_t)y * WW + lane] : 0ull;
                 dc[k] = ok ? out[(size_t)y * WW + lane] : 0ull;
             }
         };
         load1(0, nb, nc);
-        for (int k0 = 0; k0 < nrows; k0 += CHUNK) {
+        for (int k0 = 0; k0 < mine; k0 += CHUNK) {
             unsigned long long bgc[CHUNK], curc[CHUNK];
 #pragma unroll
             for (int k = 0; k < CHUNK; k++) { bgc[k] = nb[k]; curc[k] = nc[k]; }
-            if (k0 + CHUNK < nrows) load1(k0 + CHUNK, nb, nc);
+            if (k0 + CHUNK < mine) load1(k0 + CHUNK, nb, nc);
 #pragma unroll
             for (int k = 0; k < CHUNK; k++) {
                 const int kk = k0 + k;
-                if (kk >= nrows) break;
-                const int y = upw ? r.y1 - kk : r.y0 + kk;
+                if (kk >= mine) break;
+                const int y = upw ? yb - kk : ya + kk;
                 const unsigned long long bg = bgc[k], cur = curc[k];
                 const unsigned long long seed = cur | (prev & bg);
                 unsigned long long o = cur;
@@ -783,19 +809,28 @@ __global__ __launch_bounds__(64) void k_outside_flood(const uint8_t *__restrict_
                 prev = o;
             }
         }
-        if (!__ballot(any)) { converged = true; break; }
+        // a round = an upward and a downward sweep (passes 2q - 1 and 2q); s_any[q & 1] collects its changes
+        const int slot = ((pass + 1) >> 1) & 1;
+        if (__ballot(any) && lane == 0) atomicOr(&s_any[slot], 1);
+        __syncthreads();
+        if (!upw) {                                  // end of a round
+            const int ch = s_any[slot];
+            __syncthreads();
+            if (threadIdx.x == 0) s_any[slot] = 0;   // next used two rounds on: the barriers in between order the reset
+            if (!ch) { converged = true; break; }
+        }
     }
     // a background that still grows after FLOOD_MAX_PASSES alternating sweeps (a spiral thousands of turns deep) would
     // leave components wrongly classified as nested: report the frame instead of altering it silently
-    if (!converged && lane == 0) set_overflow(st[f], OVF_TRACE);
+    if (!converged && threadIdx.x == 0) set_overflow(st[f], OVF_TRACE);
 }
 
 int outside_flood(const uint8_t *mask, int n, int h, int w, FrameState *st, int use_rect, unsigned long long *bgw,
-                  unsigned long long *out, size_t plane_words, hipStream_t s)
+                  unsigned long long *out, size_t plane_words, hipStream_t s, const uint32_t *bits)
 {
     CPE_CHECK_ARG(w <= 4096 && plane_words >= (size_t)h * ((w + 63) >> 6), "outside_flood: frame too wide or scratch too small");
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_outside_flood, dim3(n), dim3(64), 0, s, mask, h, w, st, use_rect, bgw, out, plane_words);
+    CPE_KLAUNCH(k_outside_flood, dim3(n), dim3(64 * FLOOD_BANDS), 0, s, mask, h, w, st, use_rect, bgw, out, plane_words, bits);
     CPE_CHECK_LAUNCH("k_outside_flood");
     return CPE_OK;
 }

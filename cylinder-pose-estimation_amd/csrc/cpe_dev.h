@@ -132,10 +132,12 @@ __device__ __forceinline__ int *root_counter(FrameState &S, int sel)
 // (64 j + b, y) is background and 4-connected to the window border.  bgw / out: n * plane_words u64 of scratch each,
 // plane_words >= h * ceil(w / 64).
 // Frames up to 4096 columns wide (one wavefront holds a row as 64 words of 64 pixels; wider frames are refused with
-// CPE_ERR_ARG by the callers' argument check).  A flood that has not converged after FLOOD_MAX_PASSES sweeps sets OVF_TRACE.
-constexpr int FLOOD_MAX_PASSES = 4096;
+// CPE_ERR_ARG by the callers' argument check).  A flood that has not converged after FLOOD_MAX_PASSES sweeps sets OVF_TRACE
+// (a sweep walks one band of rows, a sixteenth of the window: 65536 of them are the 4096 whole-window sweeps of round 2).
+constexpr int FLOOD_MAX_PASSES = 65536;
+// bits (optional): the mask's one-bit plane (build_bitplanes with one plane per frame); the first sweep reads it instead of the bytes
 int outside_flood(const uint8_t *mask, int n, int h, int w, FrameState *st, int use_rect, unsigned long long *bgw,
-                  unsigned long long *out, size_t plane_words, hipStream_t s);
+                  unsigned long long *out, size_t plane_words, hipStream_t s, const uint32_t *bits = nullptr);
 // a component (raster-first pixel `root`) is external iff the pixel west of that pixel is outer background
 // (cv2.findContours(RETR_EXTERNAL) drops the components that lie in a hole of another one)
 __device__ __forceinline__ bool comp_is_external(const unsigned long long *out_f, int w, int root, int win_x0)

@@ -1299,7 +1299,7 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
         if (rc == CPE_ERR_ARG) rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel);
         if (rc != CPE_OK) return rc;
         unsigned long long *fl_bg = fl_plane(2 + 2 * which), *fl_out = fl_plane(3 + 2 * which);
-        if ((rc = outside_flood(base, n, h, w, st, 2, fl_bg, fl_out, fl_words, q)) != CPE_OK) return rc;
+        if ((rc = outside_flood(base, n, h, w, st, 2, fl_bg, fl_out, fl_words, q, bits)) != CPE_OK) return rc;
         if (planar) CPE_KLAUNCH((k_seg_trace<8, 700>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs, (const unsigned long long *)fl_out, fl_words);
         else CPE_KLAUNCH((k_seg_trace<5, 200>), dim3(frame_waves(n, 32, 512), n), dim3(64), 0, q, (const uint32_t *)bits, h, w, which, (const int *)roots, sel, st, segs, (const unsigned long long *)fl_out, fl_words);
         CPE_KLAUNCH(k_seg_global, dim3(n), dim3(256), 0, q, st, which, (const SegRec *)segs);

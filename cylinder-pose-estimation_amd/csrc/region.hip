@@ -1001,8 +1001,12 @@ __device__ __forceinline__ SwBlock sw_block(int n, int per_frame)
 }
 inline unsigned sw_grid(int n, int per_frame) { return (unsigned)(n * per_frame); }
 
+// Membership of the neighbours comes from the one-bit planes of the thresholds (planes[t] = img > 50 + 10 t, built for the
+// border tracers anyway): member plane pm, and plane po for "was a member before this step" (po < 0: nobody was).  A list
+// holds ~2 % of the rectangle's pixels, so the eight neighbour bytes of an entry were three 64-byte lines of the image of
+// its own; the same rows of a bit plane are shared by the ~10 entries of 512 pixels.
 template <bool DARK>
-__device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
+__device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint32_t *__restrict__ bits, int pm, int po, int h, int w, int bucket,
                                               const FrameState *__restrict__ st, const int *__restrict__ sw,
                                               const int *__restrict__ bk, int *__restrict__ P)
 {
@@ -1011,7 +1015,10 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint8_t *_
     const int nb = S[SW_BS + bucket];
     const int *list = bk + f * N + S[SW_BO + bucket];
     const SwRect r = sw_rect(st, f);
-    const uint8_t *im = img + f * N;
+    const int ws = bit_row_words(w);
+    const size_t plane_words = (size_t)h * ws;
+    const uint32_t *bm = bits + (f * NTHR + pm) * plane_words;
+    const uint32_t *bo = bits + (f * NTHR + (po < 0 ? pm : po)) * plane_words;
     int *Pf = P + f * N;
     // A pair of adjacent members is united by the newer pixel (the later one in raster order when both are new).
     // Horizontal pairs always; a vertical pair only if the pair one column to the left is not also a member pair
@@ -1021,8 +1028,6 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint8_t *_
     // k_sw_new's init pass) share their unions: each lane looks up the roots of its own partners, the run takes the
     // smallest of them, and only the run's first lane links the run to it.  Lane by lane the same unions were one
     // memory-side atomic per pixel -- the lanes of a wavefront all read "not linked yet" before any of them links.
-    auto mem = [&](int u) { return DARK ? (u <= hi) : (u > lo); };
-    auto old = [&](int u) { return DARK ? (u <= lo) : (u > hi); };
     const int lane = threadIdx.x & 63;
     for (int e0 = vb.bx * 256; e0 < nb; e0 += vb.gx * 256) {   // wave-uniform: the shuffles below need every lane
         const int e = e0 + threadIdx.x;
@@ -1032,24 +1037,32 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint8_t *_
         if (i >= 0) {
             const int y = i / w, x = i - y * w;
             const bool Lb = x > r.x0, Rb = x < r.x1, Ub = y > r.y0, Db = y < r.y1;
-            auto lvl = [&](bool ok, int q) { return ok ? (int)im[q] : (DARK ? 256 : -1); };   // outside the rectangle: never a member
-            const int vL = lvl(Lb, i - 1), vR = lvl(Rb, i + 1), vU = lvl(Ub, i - w), vD = lvl(Db, i + w);
-            const int vUL = lvl(Ub && Lb, i - w - 1), vDL = lvl(Db && Lb, i + w - 1);
-            const bool mL = mem(vL), mU = mem(vU), mD = mem(vD);
+            // three-column windows (bit 0: x - 1, bit 1: x, bit 2: x + 1; pixel x is bit x + 32 of its plane row) of the rows
+            // y - 1 .. y + 1; columns / rows outside the rectangle are never members
+            const int sh = (x + 31) & 31;
+            const size_t wo = (size_t)y * ws + ((x + 31) >> 5);
+            const unsigned cm = (Lb ? 1u : 0u) | 2u | (Rb ? 4u : 0u);
+            auto win = [&](const uint32_t *pl, long long drow) -> unsigned {
+                const unsigned long long v = *reinterpret_cast<const u64_a4 *>(pl + wo + drow * ws);
+                const unsigned b = (unsigned)(v >> sh);
+                return (DARK ? ~b : b) & cm;
+            };
+            const unsigned mu = Ub ? win(bm, -1) : 0u, mc = win(bm, 0), md = Db ? win(bm, 1) : 0u;
+            const unsigned oc = po < 0 ? 0u : win(bo, 0), od = (po < 0 || !Db) ? 0u : win(bo, 1);
+            const bool mL = mc & 1u, mU = mu & 2u, mD = md & 2u;
             if (mL && !prel) pr[np++] = i - 1;
-            if (old(vR)) pr[np++] = i + 1;
-            if (mU && !(mL && mem(vUL))) pr[np++] = i - w;
-            if (old(vD) && !(mL && mem(vDL))) pr[np++] = i + w;
+            if (oc & 4u) pr[np++] = i + 1;
+            if (mU && !(mL && (mu & 1u))) pr[np++] = i - w;
+            if ((od & 2u) && !(mL && (md & 1u))) pr[np++] = i + w;
             if (!DARK) {
-                const int vUR = lvl(Ub && Rb, i - w + 1), vDR = lvl(Db && Rb, i + w + 1);
-                const bool mR = mem(vR);
+                const bool mR = mc & 4u;
                 if (!mU) {
-                    if (mem(vUR) && !mR) pr[np++] = i - w + 1;
-                    if (mem(vUL) && !mL) pr[np++] = i - w - 1;
+                    if ((mu & 4u) && !mR) pr[np++] = i - w + 1;
+                    if ((mu & 1u) && !mL) pr[np++] = i - w - 1;
                 }
                 if (!mD) {
-                    if (old(vDR) && !mR) pr[np++] = i + w + 1;
-                    if (old(vDL) && !mL) pr[np++] = i + w - 1;
+                    if ((od & 4u) && !mR) pr[np++] = i + w + 1;
+                    if ((od & 1u) && !mL) pr[np++] = i + w - 1;
                 }
             }
         }
@@ -1273,7 +1286,7 @@ __device__ __forceinline__ void sw_snap_body(const SwBlock vb, int2 *__restrict_
 // instead of 135, and the short list walks (a few hundred entries per frame) no longer pay a launch of their own.
 template <bool DARK>
 __global__ __launch_bounds__(256) void k_sw_unite_snap(int n, int g_unite, int g_snap,
-                                                       const uint8_t *__restrict__ img, int h, int w, int lo, int hi, int bucket,
+                                                       const uint32_t *__restrict__ bits, int pm, int po, int h, int w, int bucket,
                                                        const FrameState *__restrict__ st, const int *__restrict__ bk, int *__restrict__ P,
                                                        int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int snap_slot,
                                                        const int *__restrict__ acc, int2 *__restrict__ trace, FrameState *__restrict__ stw)
@@ -1282,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_sw_unite_snap(int n, int g_unite, int g
     if (vb.f < 0) return;
     if (vb.bx < g_unite) {
         vb.gx = g_unite;
-        sw_unite_body<DARK>(vb, img, h, w, lo, hi, bucket, st, (const int *)sw, bk, P);
+        sw_unite_body<DARK>(vb, bits, pm, po, h, w, bucket, st, (const int *)sw, bk, P);
     } else {
         vb.bx -= g_unite; vb.gx = g_snap;
         sw_snap_body(vb, lists, sw, cnt_base, snap_slot, h, w, acc, trace, stw);
@@ -1696,14 +1709,15 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         (void)hipEventRecord(side->clahe_done, s);
         (void)hipStreamWaitEvent(side->s, side->clahe_done, 0);
         if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, side->s)) != CPE_OK) return rc;
-    }
+        (void)hipEventRecord(side->traced, side->s);   // the bright sweep on `s` reads them too (k_sw_unite_snap)
+    } else if ((rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
     // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
     // every brighter set and every hole of every binarisation lies inside it
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
     const int swcap = std::max(32768, (int)std::min<long long>(1 << 20, (long long)N / 12));   // grid sizing only: entries one threshold may hold
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(getenv("CPE_SW_GBK") ? atoi(getenv("CPE_SW_GBK")) : std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1732,8 +1746,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (int)(sizeof(FrameState) / sizeof(int)), -1);
         } else {
             // unions of the pixels that join at this threshold | totals of the previous threshold frozen
-            CPE_KLAUNCH(k_sw_unite_snap<true>, dim3(sw_grid(n_grid, g_bk + g_list)), dim3(256), 0, ds, nx, g_bk, g_list, (const uint8_t *)B.cl, h, w,
-                        thr - 10, thr, k, (const FrameState *)st, (const int *)B.bk, B.lab, B.hl, B.sw, (int)SW_NH, k - 1,
+            CPE_KLAUNCH(k_sw_unite_snap<true>, dim3(sw_grid(n_grid, g_bk + g_list)), dim3(256), 0, ds, nx, g_bk, g_list, (const uint32_t *)B.bits, k, k - 1, h, w,
+                        k, (const FrameState *)st, (const int *)B.bk, B.lab, B.hl, B.sw, (int)SW_NH, k - 1,
                         (const int *)B.cnt, B.tl, st);
             CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
@@ -1746,7 +1760,6 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_sw_snap, dim3(sw_grid(n_grid, g_list)), dim3(256), 0, ds, nx, g_list, B.hl, B.sw, (int)SW_NH, NTHR - 1, h, w, (const int *)B.cnt, B.tl, st);
     {
         // hole borders of all thresholds and their radii
-        if (!side && (rc = build_bitplanes(B.cl, n, h, w, 50, 10, NTHR, B.bits, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_blob_trace<1>, gtrace_h, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
                     B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
         CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
@@ -1757,13 +1770,13 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
     (void)hipMemsetAsync(B.htime, 0xFF, total, s);
+    if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
     CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
                 (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0, B.hpar, B.htime,
                 (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, 0);
     for (int j = 0; j < NTHR; j++) {
-        const int k = NTHR - 1 - j, thr = 50 + 10 * k;
-        const int hi = j == 0 ? 255 : thr + 10;
-        CPE_KLAUNCH(k_sw_unite_snap<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, (const uint8_t *)B.cl, h, w, thr, hi, k + 1,
+        const int k = NTHR - 1 - j;   // members: v > 50 + 10 k (plane k); members before this step: v > 60 + 10 k (plane k + 1; none at j = 0)
+        CPE_KLAUNCH(k_sw_unite_snap<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, (const uint32_t *)B.bits, k, j == 0 ? -1 : k + 1, h, w, k + 1,
                     (const FrameState *)st, (const int *)B.bk, B.lab2, (int2 *)nullptr, B.sw, 0, 0, (const int *)nullptr, (int2 *)nullptr, st);
         const int go = j > 0 ? g_list : 0;   // survivors of the previous (higher) threshold
         CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk + go)), dim3(256), 0, s, nx, g_bk, go, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
