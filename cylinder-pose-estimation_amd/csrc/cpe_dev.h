@@ -23,7 +23,7 @@ __host__ __device__ inline int sweep_pool(int h, int w, int which)
 constexpr int MAXJ = CPE_MAXJ;   // joints kept inside the region rectangle (include/cpe.h)
 constexpr int MAXB = 32768;      // blobs per threshold
 constexpr int MAXG = 32768;      // blob groups (one per unmatched blob: a noisy intensity ramp makes thousands)
-constexpr int MAXG_LDS = 2048;   // ... whose middle centres sit in k_blob_merge's LDS (48 KB); the rest are read from HBM
+constexpr int MAXG_LDS = 1024;   // ... whose middle centres sit in k_blob_merge's LDS (24 KB; a clean frame has ~500); the rest are read from HBM
 constexpr int GCAP = 48;         // centres per group (17 thresholds + same-threshold neighbours that fall into the same group)
 constexpr int MAXV = 131072;     // contour-vertex scratch (int2) per image
 constexpr int MAXL = CPE_MAXL;   // grid lines per direction (label groups of the joints: noise joints make extra ones)

@@ -95,7 +95,7 @@ Layout make_layout(int n, int h, int w)
     per[P_BEST2] = sizeof(unsigned long long);
     per[P_HPAR] = N * 4;
     per[P_HTIME] = N;
-    per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 3 * sizeof(double);
+    per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 4 * sizeof(double);   // x, y, r, next group in the grid cell
     per[P_FLJ] = (size_t)2 * h * ((w + 63) / 64) * sizeof(unsigned long long);   // joints chain: background / outer-background bit masks
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);
     per[P_HL] = (size_t)sweep_pool(h, w, SWL_DARK) * sizeof(int2);

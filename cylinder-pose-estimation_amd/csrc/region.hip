@@ -602,15 +602,32 @@ __device__ __forceinline__ int wave_min_int(int v)
     return v;
 }
 
-constexpr int MG_NT = 1024;   // threads of k_blob_merge (16 wavefronts: the group search and the pair tests are split over them)
+// The first-match search does not walk the groups: their middle centres are kept in a uniform grid over the frame (cells of
+// 64 x 64 pixels, one singly linked list of group indices per cell; a group moves when an insertion moves its middle centre
+// into another cell).  A blob joins a group only if dist < max(10, r_group, r_blob), so its candidates lie in the cells within
+// R = max(10, r_blob, largest middle-centre radius so far) + 1 of it -- 3 x 3 cells on a clean frame -- and the first match is
+// the smallest index among the candidates that pass the same test as before.  A frame with 20 000 blob groups (heavy sensor
+// noise) used to cost 0.2 - 1.5 s of all-pairs tests here; the search is now proportional to the local density.
+// LDS: 78 KB per workgroup, so two frames share a CU (a call of 400 - 450 images is one round of workgroups instead of two).
+// Only the centre lists of groups with at most MG_STAGE centres are staged in LDS for a batch (a clean frame's groups end
+// with 17, one per threshold); longer ones are updated in place in HBM by the in-order path.
+constexpr int MG_NT = 256;     // threads of k_blob_merge (4 wavefronts: cell ranges, pair tests and list traffic are split over them)
+constexpr int MG_CELLS = 1024; // grid cells (the cell edge doubles until the frame fits: 64 px at 1920 x 1200, 128 px at 3840 x 2160)
+constexpr int MG_LCAP = 24;    // centres per staged list
+constexpr int MG_STAGE = MG_LCAP - 4;
 __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
                                                     const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
-                                                    Group *__restrict__ groups, int always_replay, double *__restrict__ gmid_all)
+                                                    Group *__restrict__ groups, int always_replay, double *__restrict__ gmid_all,
+                                                    int h, int w)
 {
     // location + radius of each group's middle centre (what the tests read)
     __shared__ double sX[MAXG_LDS], sY[MAXG_LDS], sR[MAXG_LDS];   // groups >= MAXG_LDS: gmid (HBM, this workgroup only)
+    __shared__ int s_next[MAXG_LDS];                               // next group in the same grid cell (-1: none)
+    __shared__ unsigned char s_gn[MAXG_LDS];                       // centres in the group's list (G[].n, saves a round trip per batch)
+    __shared__ int s_head[MG_CELLS];
+    __shared__ double s_maxr;                                      // largest radius a middle centre ever had (search range bound)
     __shared__ double bX[64], bY[64], bR[64];
-    __shared__ double pl[GCAP * 3][64];   // centre lists of the groups the batch touches: [element][slot], lanes = slots
+    __shared__ double pl[MG_LCAP * 3][64];   // centre lists of the groups the batch touches: [element][slot], lanes = slots
     __shared__ double cX[64], cY[64], cR[64];   // middle centre each blob's group gets if the blob is inserted
     __shared__ int cG[64], s_bad[64];
     __shared__ int pn[64], pg[64], pd[64], s_jm[64], s_mod[64];
@@ -619,19 +636,56 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     FrameState &S = st[f];
     int *ord = order + (size_t)f * MAXB;
     Group *G = groups + (size_t)f * MAXG;
-    double *gm = gmid_all + (size_t)f * (MAXG - MAXG_LDS) * 3 - (size_t)MAXG_LDS * 3;   // gm[3 j ..] for j >= MAXG_LDS
+    double *gm = gmid_all + (size_t)f * (MAXG - MAXG_LDS) * 4 - (size_t)MAXG_LDS * 4;   // gm[4 j ..] = x, y, r, next for j >= MAXG_LDS
+    // HBM entries are written by other wavefronts of this workgroup between barriers: read past the vector L1
+    auto gm_load = [&](int j, int k) { return __hip_atomic_load(gm + 4 * (size_t)j + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto mid_joins = [&](int j, double cx, double cy, double cr) {
         if (j < MAXG_LDS) return blob_joins(sX[j], sY[j], sR[j], cx, cy, cr);
-        // written by other wavefronts of this workgroup between barriers: read past the vector L1
-        const double gx = __hip_atomic_load(gm + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double gy = __hip_atomic_load(gm + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double gr = __hip_atomic_load(gm + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return blob_joins(gx, gy, gr, cx, cy, cr);
+        return blob_joins(gm_load(j, 0), gm_load(j, 1), gm_load(j, 2), cx, cy, cr);
     };
     auto mid_set = [&](int j, double x, double y, double r) {
         if (j < MAXG_LDS) { sX[j] = x; sY[j] = y; sR[j] = r; }
-        else { gm[3 * j] = x; gm[3 * j + 1] = y; gm[3 * j + 2] = r; }
+        else { gm[4 * (size_t)j] = x; gm[4 * (size_t)j + 1] = y; gm[4 * (size_t)j + 2] = r; }
     };
+    // ---- the grid over the middle centres
+    int cs = 64;
+    while (((w + cs - 1) / cs) * ((h + cs - 1) / cs) > MG_CELLS) cs *= 2;
+    const int gw = (w + cs - 1) / cs, gh = (h + cs - 1) / cs;
+    const double inv_cs = 1.0 / cs;                       // a power of two: the scaling is exact
+    auto cell_x = [&](double x) { return min(max((int)floor(x * inv_cs), 0), gw - 1); };
+    auto cell_y = [&](double y) { return min(max((int)floor(y * inv_cs), 0), gh - 1); };
+    auto cell_of = [&](double x, double y) { return cell_y(y) * gw + cell_x(x); };
+    auto mid_cell = [&](int j) { return j < MAXG_LDS ? cell_of(sX[j], sY[j]) : cell_of(gm_load(j, 0), gm_load(j, 1)); };
+    auto nxt_get = [&](int j) { return j < MAXG_LDS ? s_next[j] : (int)gm_load(j, 3); };
+    auto nxt_set = [&](int j, int v) { if (j < MAXG_LDS) s_next[j] = v; else gm[4 * (size_t)j + 3] = (double)v; };
+    auto grid_link = [&](int j, int c) { nxt_set(j, atomicExch(&s_head[c], j)); };   // any number of lanes of ONE wavefront at a time
+    auto grid_unlink = [&](int j, int c) {                                            // one lane at a time
+        int p = s_head[c];
+        if (p == j) { s_head[c] = nxt_get(j); return; }
+        for (int it = 0; p >= 0 && it < MAXG; it++) {   // (a list never holds more than every group: the walk ends whatever it reads)
+            const int q = nxt_get(p);
+            if (q == j) { nxt_set(p, nxt_get(j)); return; }
+            p = q;
+        }
+    };
+    // smallest group index < limit among the candidates in this caller's share of the cells around (cx, cy) that the blob
+    // joins (INT_MAX: none); the cells of the range are dealt out in turns: share `part` of `nsplit`
+    auto grid_first = [&](double cx, double cy, double cr, int limit, int part, int nsplit) {
+        const double R = fmax(fmax(10.0, cr), s_maxr) + 1.0;
+        const int x0 = cell_x(cx - R), x1 = cell_x(cx + R), y0 = cell_y(cy - R), y1 = cell_y(cy + R);
+        int first = INT_MAX, k = 0;
+        for (int yy = y0; yy <= y1; yy++)
+            for (int xx = x0; xx <= x1; xx++, k++) {
+                if (k % nsplit != part) continue;
+                int it = 0;
+                for (int g = s_head[yy * gw + xx]; g >= 0 && it < MAXG; g = nxt_get(g), it++)
+                    if (g < limit && g < first && mid_joins(g, cx, cy, cr)) first = g;
+            }
+        return first;
+    };
+    for (int c = t; c < MG_CELLS; c += MG_NT) s_head[c] = -1;
+    if (t == 0) s_maxr = 0.0;
+    __syncthreads();
     int ng = 0;
     for (int thr = 0; thr < NTHR; thr++) {
         const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + thr], MAXB);
@@ -658,22 +712,14 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 s_jm[t] = INT_MAX; pg[t] = -1; pd[t] = 0;
             }
             __syncthreads();
-            // 1. first match against the state at the start of the batch: lane = blob, each wavefront walks a sixteenth
-            //    of the groups (their centres are LDS broadcasts)
-            {
-                const int per = (ng0 + MG_NT / 64 - 1) / (MG_NT / 64), jlo = (t >> 6) * per, jhi = min(jlo + per, ng0);
+            // 1. first match against the state at the start of the batch: lane = blob, the wavefronts take the cells around
+            //    the blob in turns
+            if (ng0 > 0) {
                 const bool act = lane < qn;
-                const double cx = act ? bX[lane] : 0, cy = act ? bY[lane] : 0, cr = act ? bR[lane] : 0;
-                int first = act ? INT_MAX : -1;
-                for (int j = jlo; j < jhi; j += 4) {   // four groups per round: their centres are read together
-                    int hit = INT_MAX;
-#pragma unroll
-                    for (int u = 3; u >= 0; u--)
-                        if (j + u < jhi && mid_joins(j + u, cx, cy, cr)) hit = j + u;
-                    first = min(first, hit);
-                    if (!__ballot(first == INT_MAX)) break;
+                if (act) {
+                    const int first = grid_first(bX[lane], bY[lane], bR[lane], ng0, t >> 6, MG_NT / 64);
+                    if (first != INT_MAX) atomicMin(&s_jm[lane], first);
                 }
-                if (act && first != INT_MAX) atomicMin(&s_jm[lane], first);
             }
             __syncthreads();
             // 2. one LDS slot per distinct group (slot = first blob of the batch that found it), filled together
@@ -687,10 +733,13 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 if (first) pg[t] = g;
             }
             __syncthreads();
-            // list lengths first (one round trip), then only the entries in use, every thread's loads in flight together
+            // list lengths first (LDS; one round trip for the groups beyond it), then only the entries in use, every thread's
+            // loads in flight together.  A list too long for the staging area is not staged: its blob is then not "clean",
+            // and the in-order path updates the list where it lies
             if (t < 64) {
-                const int g = pg[t];
-                const int gn = g >= 0 ? G[g].n : 0;
+                int g = pg[t];
+                int gn = g >= 0 ? (g < MAXG_LDS ? (int)s_gn[g] : G[g].n) : 0;
+                if (gn > MG_STAGE) { pg[t] = -1; g = -1; gn = 0; }
                 pn[t] = gn;
                 int mx = gn;
                 for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
@@ -698,7 +747,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
             }
             __syncthreads();
             {
-                const int per = 3 * s_maxn;                      // doubles per slot to look at (<= GCAP * 3)
+                const int per = 3 * s_maxn;                      // doubles per slot to look at (<= MG_STAGE * 3)
                 for (int idx0 = 0; idx0 < 64 * per; idx0 += 4 * MG_NT) {
                     double v[4];
                     int qq[4], ee[4];
@@ -760,13 +809,19 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                 const bool serial = always_replay || (clean < qn && clean < 8);
                 if (!serial) {
                     const bool mine = lane < clean;
+                    int link_g = -1, link_c = 0, old_c = -1;   // grid: group to (re)link into cell link_c; old_c >= 0: it leaves that cell
+                    double newr = 0.0;
                     if (mine && ins) {
                         for (int k = gn - 1; k >= pos; k--) {
                             pl[3 * k + 3][lane] = pl[3 * k][lane]; pl[3 * k + 4][lane] = pl[3 * k + 1][lane]; pl[3 * k + 5][lane] = pl[3 * k + 2][lane];
                         }
                         pl[3 * pos][lane] = cx; pl[3 * pos + 1][lane] = cy; pl[3 * pos + 2][lane] = cr;
                         pn[lane] = gn + 1; pd[lane] = 1;
+                        if (jm < MAXG_LDS) s_gn[jm] = (unsigned char)(gn + 1);
+                        const int c0 = mid_cell(jm), c1 = cell_of(nx, ny);
+                        if (c0 != c1) { link_g = jm; link_c = c1; old_c = c0; }
                         mid_set(jm, nx, ny, nr);
+                        newr = nr;
                     }
                     if (mine && full) set_overflow(S, OVF_GROUPS);
                     const bool fresh = mine && jm == INT_MAX;
@@ -778,8 +833,18 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                             g.n = 1;
                             g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
                             mid_set(gi, cx, cy, cr);
+                            if (gi < MAXG_LDS) s_gn[gi] = 1;
+                            link_g = gi; link_c = cell_of(cx, cy);
+                            newr = cr;
                         } else set_overflow(S, OVF_GROUPS);
                     }
+                    // grid upkeep by this one wavefront: the groups that change cell leave their lists one after the other,
+                    // then every lane with a moved or a new group links it in (atomic exchange on the cell head)
+                    for (unsigned long long mb = __ballot(old_c >= 0); mb; mb &= mb - 1ull)
+                        if (lane == __ffsll((long long)mb) - 1) grid_unlink(link_g, old_c);
+                    if (link_g >= 0) grid_link(link_g, link_c);
+                    for (int off = 32; off >= 1; off >>= 1) newr = fmax(newr, __shfl_xor(newr, off, 64));
+                    if (t == 0 && newr > s_maxr) s_maxr = newr;
                     ng = min(ng + __popcll(fb), MAXG);
                     if (t == 0) { s_ng = ng; s_adv = clean; }
                 } else if (t == 0) s_adv = qn;
@@ -789,15 +854,14 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
             if (t < 64 && s_serial) {
                 int nm = 0;
                 for (int q = 0; q < qn; q++) {
+                    // (a staged list is full -- a fifth blob of this batch for one group: the batch ends in front of this blob,
+                    //  the next one finds the list too long to stage and updates it in HBM)
                     const double cx = bX[q], cy = bY[q], cr = bR[q];
                     int jm = s_jm[q];
                     const int mj = lane < nm ? s_mod[lane] : -1;
                     const bool changed = jm != INT_MAX && __ballot(mj == jm) != 0ull;
                     if (changed) {
-                        int jmin = INT_MAX;
-                        for (int j = lane; j < ng0; j += 64)
-                            if (mid_joins(j, cx, cy, cr)) jmin = min(jmin, j);
-                        jm = wave_min_int(jmin);
+                        jm = wave_min_int(grid_first(cx, cy, cr, ng0, lane, 64));   // the cells around the blob, one per lane
                     } else {
                         int cand = INT_MAX;
                         if (mj >= 0 && mj < jm && mid_joins(mj, cx, cy, cr)) cand = mj;
@@ -808,13 +872,16 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                         const int slot = sb ? __ffsll((long long)sb) - 1 : -1;
                         Group &g = G[jm];
                         const int gn = slot >= 0 ? pn[slot] : g.n;
+                        if (slot >= 0 && gn >= MG_LCAP) {
+                            if (lane == 0) s_adv = q;
+                            break;
+                        }
                         if (gn < GCAP) {
                             // insertion behind the last centre whose radius is not larger (the list is sorted by radius)
                             double ex = 0, ey = 0, er = 0;
-                            if (lane < GCAP) {
-                                if (slot >= 0) { ex = pl[3 * lane][slot]; ey = pl[3 * lane + 1][slot]; er = pl[3 * lane + 2][slot]; }
-                                else { ex = g.c[lane][0]; ey = g.c[lane][1]; er = g.c[lane][2]; }
-                            }
+                            if (slot >= 0) {
+                                if (lane < MG_LCAP) { ex = pl[3 * lane][slot]; ey = pl[3 * lane + 1][slot]; er = pl[3 * lane + 2][slot]; }
+                            } else if (lane < GCAP) { ex = g.c[lane][0]; ey = g.c[lane][1]; er = g.c[lane][2]; }
                             const int pos = __popcll(__ballot(lane < gn && !(cr < er)));
                             const int m = (gn + 1) / 2;
                             const int src = m < pos ? m : m - 1;   // element of the old list that becomes the middle one
@@ -831,7 +898,13 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                                 if (lane >= pos && lane < gn) { g.c[lane + 1][0] = ex; g.c[lane + 1][1] = ey; g.c[lane + 1][2] = er; }
                                 if (lane == 0) { g.c[pos][0] = cx; g.c[pos][1] = cy; g.c[pos][2] = cr; g.n = gn + 1; }
                             }
-                            if (lane == 0) mid_set(jm, sx, sy, sr);
+                            if (lane == 0) {
+                                if (jm < MAXG_LDS) s_gn[jm] = (unsigned char)(gn + 1);
+                                const int c0 = mid_cell(jm), c1 = cell_of(sx, sy);
+                                if (c0 != c1) { grid_unlink(jm, c0); grid_link(jm, c1); }
+                                mid_set(jm, sx, sy, sr);
+                                if (sr > s_maxr) s_maxr = sr;
+                            }
                             if (__ballot(mj == jm) == 0ull) {   // first change of this group in the batch
                                 if (lane == 0) s_mod[nm] = jm;
                                 nm++;
@@ -843,6 +916,9 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
                             g.n = 1;
                             g.c[0][0] = cx; g.c[0][1] = cy; g.c[0][2] = cr;
                             mid_set(ng, cx, cy, cr);
+                            if (ng < MAXG_LDS) s_gn[ng] = 1;
+                            grid_link(ng, cell_of(cx, cy));
+                            if (cr > s_maxr) s_maxr = cr;
                         }
                         ng++;
                     } else if (lane == 0) set_overflow(S, OVF_GROUPS);
@@ -1717,7 +1793,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
     const int swcap = std::max(32768, (int)std::min<long long>(1 << 20, (long long)N / 12));   // grid sizing only: entries one threshold may hold
-    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(getenv("CPE_SW_GBK") ? atoi(getenv("CPE_SW_GBK")) : std::min(SW_GRID, std::max(16, 6144 / n)), n);
+    const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
         CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
@@ -1795,7 +1871,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
         const char *e = getenv("CPE_MERGE_REPLAY");
         CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(MG_NT), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups,
-                    (e && e[0] == '1') ? 1 : 0, B.gmid);
+                    (e && e[0] == '1') ? 1 : 0, B.gmid, h, w);
     }
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);
