@@ -25,7 +25,8 @@ STATUS_TEXT = {0: 'ok', 1: 'no region (cv2.convexHull(None))', 2: 'no saturated 
 _STATE_FIELDS = ['status', 'rect0', 'rect1', 'rect2', 'rect3', 'r0', 'spot0', 'spot1', 'spot2', 'spot3', 'n_roots',
                  'n_comps', 'n_joints_all', 'n_joints', 'n_blobs', 'n_groups', 'n_groups_prev', 'n_kp', 'n_verts',
                  'n_dists', 'best_comp', 'n_seg0', 'n_seg1', 'gang0', 'gang1', 'glen0', 'glen1', 'n_rows', 'n_cols',
-                 'overflow', 'hull_n', 'crect0', 'crect1', 'crect2', 'crect3', 'nrect0', 'nrect1', 'nrect2', 'nrect3', 'n_roots_p', 'n_roots_s', 'spot_fail']
+                 'overflow', 'hull_n', 'crect0', 'crect1', 'crect2', 'crect3', 'nrect0', 'nrect1', 'nrect2', 'nrect3', 'n_roots_p', 'n_roots_s', 'spot_fail',
+                 'srect0', 'srect1', 'srect2', 'srect3']
 
 
 class DetectWorkspace:

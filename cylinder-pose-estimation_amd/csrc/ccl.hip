@@ -38,7 +38,8 @@ __device__ __forceinline__ Rect get_rect(const FrameState *st, size_t f, int use
     else if (use_rect == 2) {   // region rectangle (boundingRect of the hull) + 2 px: holds every mask derived from mask_contour
         const int *q = st[f].rect;
         r.x0 = max(q[0] - 2, 0); r.y0 = max(q[1] - 2, 0); r.x1 = min(q[0] + q[2] + 1, w - 1); r.y1 = min(q[1] + q[3] + 1, h - 1);
-    } else { r.x0 = 0; r.y0 = 0; r.x1 = w - 1; r.y1 = h - 1; }
+    } else if (use_rect == 3) { r.x0 = st[f].srect[0]; r.y0 = st[f].srect[1]; r.x1 = st[f].srect[2]; r.y1 = st[f].srect[3]; }   // spot window (may be empty)
+    else { r.x0 = 0; r.y0 = 0; r.x1 = w - 1; r.y1 = h - 1; }
     return r;
 }
 
@@ -284,9 +285,10 @@ __global__ __launch_bounds__(256) void k_ccl_roots64(SRC src0, int h, int w,
     const int *Lf = L + f * N;
     const int sy = gi / WW, j = gi - sy * WW, x0 = j * 64;
     const bool live = gi < WW * strips && !(r.x1 < r.x0 || x0 > r.x1 || x0 + 63 < r.x0);
-    const int ya = max(sy * CCL_STRIP, r.y0), yb = live ? min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1) : -1;
-    const unsigned long long cmask = col_mask64(x0, r.x0, r.x1);
-    const bool hasL = x0 - 1 >= r.x0;
+    // (an empty rectangle may be INT_MAX .. -1: nothing of it enters the row arithmetic unless `live`)
+    const int ya = live ? max(sy * CCL_STRIP, r.y0) : 0, yb = live ? min(sy * CCL_STRIP + CCL_STRIP - 1, r.y1) : -1;
+    const unsigned long long cmask = live ? col_mask64(x0, r.x0, r.x1) : 0ull;
+    const bool hasL = live && x0 - 1 >= r.x0;
     for (int k = 0; k < CCL_STRIP; k++) {     // wave-uniform trip count: the appends below are wavefront collectives
         const int y = ya + k;
         unsigned long long starts = 0;

@@ -70,6 +70,7 @@ struct FrameState {
     int n_roots_p;      // component count of the joints labelling (runs on its own stream, beside the region stage)
     int n_roots_s;      // component count of the spot labelling (third stream)
     int spot_fail;      // the spot chain found no saturated spot: folded into `status` when the chains join
+    int srect[4];       // window of the spot labelling (x0, y0, x1, y1): the tiles that hold a pixel > 240, + 16 px
 };
 
 struct SegRec { float p1x, p1y, p2x, p2y, angle, len; int valid; int pad; };

@@ -377,83 +377,18 @@ struct Taps { int k[19]; int r; int shift; };
 //   BLUR_RECT (7x7): only the box means around the intersection points are read (find_center_point, :1548-1560), and
 //     those points lie inside the region rectangle: tiles away from rect +- (half + 1) are left untouched.
 constexpr int BT_X = 64, BT_Y = 32;
-enum { BLUR_SPOT = 0, BLUR_RECT = 1 };
-template <int R, int MODE>
-__global__ __launch_bounds__(256) void k_blur_fused(const uint8_t *__restrict__ src, int h, int w, int tiles_x, int tiles_y, Taps t,
-                                                    const FrameState *__restrict__ st, uint8_t *__restrict__ dst)
+// one BT_X x BT_Y tile: both passes through LDS (workgroup-wide; ends with the stores, no barrier after them)
+template <int R>
+__device__ __forceinline__ void blur_tile(const uint8_t *__restrict__ im, int h, int w, int gx0, int gy0, const Taps &t,
+                                          uint8_t *__restrict__ out, uint8_t *s_in, uint16_t *s_h)
 {
     constexpr int IW = BT_X + 2 * R, IH = BT_Y + 2 * R;
-    __shared__ uint8_t s_in[IH * IW];
-    __shared__ uint16_t s_h[IH * BT_X];
-    __shared__ int s_max;
     const int tid = threadIdx.x;
-    const int tiles = tiles_x * tiles_y;
-    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
-    const int gx0 = (tt % tiles_x) * BT_X, gy0 = (tt / tiles_x) * BT_Y;
-    const size_t N = (size_t)h * w;
-    if (MODE == BLUR_RECT) {
-        const FrameState &S = st[f];
-        if (S.status != CPE_ST_OK) return;
-        int half = (int)(S.r0 / 5.0);
-        if (half < 3) half = 3;
-        if (half > 10) half = half + 5;
-        half = max(half, (int)(S.r0 / 4.5));   // the planar script's window (util_plane.py:1280)
-        const int m = half + 1;
-        if (gx0 > S.rect[0] + S.rect[2] + m || gx0 + BT_X < S.rect[0] - m || gy0 > S.rect[1] + S.rect[3] + m ||
-            gy0 + BT_Y < S.rect[1] - m)
-            return;
-    }
-    if (tid == 0) s_max = 0;
-    __syncthreads();
-    const uint8_t *im = src + f * N;
-    if (MODE == BLUR_SPOT) {
-        // quick look first: the tile and a 12-pixel apron (a superset of the 9 the blur reads, starting on a dword) hold no
-        // pixel > 240 -> the tile is 0.  Dword loads, 16-byte stores; tiles near the frame border take the general path.
-        const int ax0 = gx0 - 12, ay0 = gy0 - R;
-        constexpr int QW = (BT_X + 24) / 4;
-        if (ax0 >= 0 && ax0 + 4 * QW <= w && ay0 >= 0 && ay0 + IH <= h && gy0 + BT_Y <= h && (w & 15) == 0 &&
-            ((((size_t)im) | ((size_t)dst)) & 15) == 0) {
-            uint32_t any = 0;
-            for (int i = tid; i < IH * QW; i += 256) {
-                const int ry = i / QW, q = i - ry * QW;
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(im + (size_t)(ay0 + ry) * w + ax0 + 4 * q);
-                // a byte > 240 <=> (byte + 15) carries into bit 8 of its own 9-bit field: test the two byte pairs apart
-                const uint32_t lo = (v & 0x00FF00FFu) + 0x000F000Fu, hi = ((v >> 8) & 0x00FF00FFu) + 0x000F000Fu;
-                any |= (lo | hi) & 0x01000100u;
-            }
-            if (__ballot(any != 0) != 0 && (tid & 63) == 0) atomicMax(&s_max, 255);
-            __syncthreads();
-            if (s_max == 0) {
-                for (int i = tid; i < BT_Y * (BT_X / 16); i += 256) {
-                    const int ry = i / (BT_X / 16), q = i - ry * (BT_X / 16);
-                    *reinterpret_cast<uint4 *>(dst + f * N + (size_t)(gy0 + ry) * w + gx0 + 16 * q) = make_uint4(0, 0, 0, 0);
-                }
-                return;
-            }
-            __syncthreads();
-            if (tid == 0) s_max = 0;
-            __syncthreads();
-        }
-    }
-    int mx = 0;
     for (int i = tid; i < IH * IW; i += 256) {
         int ry = i / IW, rx = i - ry * IW;
-        int v = im[(size_t)reflect101(gy0 - R + ry, h) * w + reflect101(gx0 - R + rx, w)];
-        s_in[i] = (uint8_t)v;
-        mx = max(mx, v);
-    }
-    if (MODE == BLUR_SPOT) {
-        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-        if ((tid & 63) == 0) atomicMax(&s_max, mx);
+        s_in[i] = im[(size_t)reflect101(gy0 - R + ry, h) * w + reflect101(gx0 - R + rx, w)];
     }
     __syncthreads();
-    if (MODE == BLUR_SPOT && s_max <= 240) {
-        for (int i = tid; i < BT_Y * BT_X; i += 256) {
-            int ry = i / BT_X, rx = i - ry * BT_X;
-            if (gy0 + ry < h && gx0 + rx < w) dst[f * N + (size_t)(gy0 + ry) * w + gx0 + rx] = 0;
-        }
-        return;
-    }
     for (int i = tid; i < IH * BT_X; i += 256) {
         int ry = i / BT_X, rx = i - ry * BT_X;
         const uint8_t *p = &s_in[ry * IW + rx];
@@ -470,7 +405,167 @@ __global__ __launch_bounds__(256) void k_blur_fused(const uint8_t *__restrict__ 
 #pragma unroll
         for (int j = 0; j <= 2 * R; j++) sacc += t.k[j] * (int)p[j * BT_X];
         if (gy0 + ry < h && gx0 + rx < w)
-            dst[f * N + (size_t)(gy0 + ry) * w + gx0 + rx] = (uint8_t)((sacc + (1 << (t.shift - 1))) >> t.shift);
+            out[(size_t)(gy0 + ry) * w + gx0 + rx] = (uint8_t)((sacc + (1 << (t.shift - 1))) >> t.shift);
+    }
+}
+
+// BLUR_RECT (7 x 7): one workgroup per tile, tiles away from the region rectangle are left untouched
+template <int R>
+__global__ __launch_bounds__(256) void k_blur_fused(const uint8_t *__restrict__ src, int h, int w, int tiles_x, int tiles_y, Taps t,
+                                                    const FrameState *__restrict__ st, uint8_t *__restrict__ dst)
+{
+    constexpr int IW = BT_X + 2 * R, IH = BT_Y + 2 * R;
+    __shared__ uint8_t s_in[IH * IW];
+    __shared__ uint16_t s_h[IH * BT_X];
+    const int tiles = tiles_x * tiles_y;
+    const int f = blockIdx.x / tiles, tt = blockIdx.x - f * tiles;
+    const int gx0 = (tt % tiles_x) * BT_X, gy0 = (tt / tiles_x) * BT_Y;
+    const size_t N = (size_t)h * w;
+    const FrameState &S = st[f];
+    if (S.status != CPE_ST_OK) return;
+    int half = (int)(S.r0 / 5.0);
+    if (half < 3) half = 3;
+    if (half > 10) half = half + 5;
+    half = max(half, (int)(S.r0 / 4.5));   // the planar script's window (util_plane.py:1280)
+    const int m = half + 1;
+    if (gx0 > S.rect[0] + S.rect[2] + m || gx0 + BT_X < S.rect[0] - m || gy0 > S.rect[1] + S.rect[3] + m ||
+        gy0 + BT_Y < S.rect[1] - m)
+        return;
+    blur_tile<R>(src + f * N, h, w, gx0, gy0, t, dst + f * N, s_in, s_h);
+}
+
+// BLUR_SPOT (19 x 19) in two steps.  k_spot_scan reads the frame once (16-byte loads, a band of BT_Y rows per workgroup) and
+// flags the tiles that hold a pixel > 240; their bounding box (+ 16 px) becomes st[].srect, the window of the spot
+// labelling.  k_blur19_spot (again a band per workgroup) writes zeros over every tile with no flagged tile among its 3 x 3
+// neighbours -- the taps sum to 2^16, so the blur is <= the largest input of its 19 x 19 window and cannot exceed 240
+// there -- and looks at the others (blur19_tile_spot).  One read and one write of the frame instead of 1.6 reads through
+// LDS per tile.  The blurred plane is only ever asked `> 240` (util_cylinder.py:1958): where that cannot hold it is 0.
+__global__ __launch_bounds__(256) void k_spot_scan(const uint8_t *__restrict__ gray, int h, int w, int tiles_x, int tiles_y,
+                                                   FrameState *__restrict__ st, uint8_t *__restrict__ flags, size_t flag_stride)
+{
+    __shared__ int s_f[128];
+    const int f = blockIdx.x / tiles_y, ty = blockIdx.x - f * tiles_y, tid = threadIdx.x;
+    const int gy0 = ty * BT_Y, rows = min(BT_Y, h - gy0);
+    if (tid < 128) s_f[tid] = 0;
+    __syncthreads();
+    const uint8_t *im = gray + (size_t)f * h * w + (size_t)gy0 * w;
+    if ((w & 15) == 0 && (((size_t)im) & 15) == 0) {
+        const int cw = w >> 4;                     // the rows of a band are contiguous: chunk i = (row i / cw, 16 columns from 16 (i % cw))
+        // a byte > 240 <=> (byte + 15) carries into bit 8 of its own 9-bit field: test the two byte pairs apart
+        auto gt = [](uint32_t d) { return (((d & 0x00FF00FFu) + 0x000F000Fu) | (((d >> 8) & 0x00FF00FFu) + 0x000F000Fu)) & 0x01000100u; };
+        for (int i = tid; i < rows * cw; i += 256) {
+            const uint4 v = reinterpret_cast<const uint4 *>(im)[i];
+            if (gt(v.x) | gt(v.y) | gt(v.z) | gt(v.w)) s_f[((i % cw) * 16) / BT_X] = 1;
+        }
+    } else {
+        for (int i = tid; i < rows * w; i += 256)
+            if (im[i] > 240) s_f[(i % w) / BT_X] = 1;
+    }
+    __syncthreads();
+    uint8_t *fl = flags + f * flag_stride + (size_t)ty * tiles_x;
+    for (int tx = tid; tx < tiles_x; tx += 256) {
+        fl[tx] = (uint8_t)s_f[tx];
+        if (s_f[tx]) {
+            FrameState &S = st[f];
+            atomicMin(&S.srect[0], max(tx * BT_X - 16, 0)); atomicMin(&S.srect[1], max(gy0 - 16, 0));
+            atomicMax(&S.srect[2], min(tx * BT_X + BT_X + 15, w - 1)); atomicMax(&S.srect[3], min(gy0 + BT_Y + 15, h - 1));
+        }
+    }
+}
+
+// One live tile of the 19 x 19 blur.  Row sums first: a thread makes 8 neighbouring sums of a row from 8 dwords of the LDS
+// window (v_alignbyte_b32 picks the four bytes that start at any byte, v_dot4_u32_u8 multiplies them with four taps: 10
+// instructions per sum instead of 19 byte reads and 19 multiply-adds).  The column pass is a weighted mean of row sums
+// (its taps add up to 256): if no row sum of the tile's rows exceeds 240 * 256 no blurred value exceeds 240, and the tile
+// keeps the zeros it already holds -- the case of nearly every live tile (the dots where two laser lines cross are > 240
+// but only ~5 px wide; it takes the saturated spot to lift a 19-tap mean over 240).  Returns after the stores, no barrier.
+__device__ __forceinline__ void blur19_tile_spot(const uint8_t *__restrict__ im, int h, int w, int gx0, int gy0, const Taps &t,
+                                                 uint8_t *__restrict__ out, uint32_t *s_in32, uint16_t *s_h, int *s_max)
+{
+    constexpr int R = 9, IH = BT_Y + 2 * R, QW = (BT_X + 24) / 4;   // LDS window: columns gx0 - 12 .. gx0 + BT_X + 11 (dword aligned)
+    const int tid = threadIdx.x;
+    const int ax0 = gx0 - 12, ay0 = gy0 - R;
+    if (tid == 0) *s_max = 0;
+    if (ax0 >= 0 && ax0 + 4 * QW <= w && ay0 >= 0 && ay0 + IH <= h && (w & 3) == 0 && (((size_t)im) & 3) == 0) {
+        for (int i = tid; i < IH * QW; i += 256) {
+            const int ry = i / QW, q = i - ry * QW;
+            s_in32[i] = *reinterpret_cast<const uint32_t *>(im + (size_t)(ay0 + ry) * w + ax0 + 4 * q);
+        }
+    } else {
+        uint8_t *s_in8 = reinterpret_cast<uint8_t *>(s_in32);
+        for (int i = tid; i < IH * QW * 4; i += 256) {
+            const int ry = i / (4 * QW), b = i - ry * 4 * QW;
+            s_in8[i] = im[(size_t)reflect101(ay0 + ry, h) * w + reflect101(ax0 + b, w)];
+        }
+    }
+    __syncthreads();
+    uint32_t T[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+        T[q] = (uint32_t)t.k[4 * q] | ((uint32_t)t.k[4 * q + 1] << 8) | ((uint32_t)t.k[4 * q + 2] << 16) | ((q < 4 ? (uint32_t)t.k[4 * q + 3] : 0u) << 24);
+    int mx = 0;
+    for (int it = tid; it < IH * (BT_X / 8); it += 256) {
+        const int ry = it / (BT_X / 8), c0 = (it - ry * (BT_X / 8)) * 8;
+        const uint32_t *dp = s_in32 + ry * QW + (c0 >> 2);   // tile column c is window byte c + 3 .. the sum of column c0 + o reads bytes c0 + o + 3 .. + 21
+        uint32_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = dp[k];
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const int sb = o + 3, idx = sb >> 2, sh = sb & 3;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[idx + q + 1], d[idx + q], sh), T[q], acc, false);
+            s_h[ry * BT_X + c0 + o] = (uint16_t)acc;
+            mx = max(mx, (int)acc);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0) atomicMax(s_max, mx);
+    __syncthreads();
+    if (*s_max <= 240 * 256) return;               // (uniform) every blurred value of the tile is <= 240: it stays 0
+    for (int i = tid; i < BT_Y * BT_X; i += 256) {
+        int ry = i / BT_X, rx = i - ry * BT_X;
+        const uint16_t *p = &s_h[ry * BT_X + rx];
+        int sacc = 0;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; j++) sacc += t.k[j] * (int)p[j * BT_X];
+        if (gy0 + ry < h && gx0 + rx < w)
+            out[(size_t)(gy0 + ry) * w + gx0 + rx] = (uint8_t)((sacc + (1 << (t.shift - 1))) >> t.shift);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blur19_spot(const uint8_t *__restrict__ src, int h, int w, int tiles_x, int tiles_y, Taps t,
+                                                     const uint8_t *__restrict__ flags, size_t flag_stride, uint8_t *__restrict__ dst)
+{
+    constexpr int R = 9, IH = BT_Y + 2 * R, QW = (BT_X + 24) / 4;
+    __shared__ uint32_t s_in32[IH * QW];
+    __shared__ uint16_t s_h[IH * BT_X];
+    __shared__ uint8_t s_live[128];
+    __shared__ int s_max;
+    const int f = blockIdx.x / tiles_y, ty = blockIdx.x - f * tiles_y, tid = threadIdx.x;
+    const int gy0 = ty * BT_Y, rows = min(BT_Y, h - gy0);
+    const size_t N = (size_t)h * w;
+    const uint8_t *fl = flags + f * flag_stride;
+    for (int tx = tid; tx < tiles_x; tx += 256) {
+        int any = 0;
+        for (int yy = max(ty - 1, 0); yy <= min(ty + 1, tiles_y - 1); yy++)
+            for (int xx = max(tx - 1, 0); xx <= min(tx + 1, tiles_x - 1); xx++) any |= fl[(size_t)yy * tiles_x + xx];
+        s_live[tx] = (uint8_t)any;
+    }
+    // zeros over the whole band; the few tiles whose blur can exceed 240 are written again below
+    uint8_t *out = dst + f * N + (size_t)gy0 * w;
+    if ((w & 15) == 0 && (((size_t)out) & 15) == 0) {
+        for (int i = tid; i < rows * (w >> 4); i += 256) reinterpret_cast<uint4 *>(out)[i] = make_uint4(0, 0, 0, 0);
+    } else {
+        for (int i = tid; i < rows * w; i += 256) out[i] = 0;
+    }
+    __syncthreads();                               // (waits for this wavefront's zero stores: the stores below come after them)
+    for (int tx = 0; tx < tiles_x; tx++) {
+        if (!s_live[tx]) continue;                 // (uniform)
+        blur19_tile_spot(src + f * N, h, w, tx * BT_X, gy0, t, dst + f * N, s_in32, s_h, &s_max);
+        __syncthreads();
     }
 }
 
@@ -1104,10 +1199,12 @@ __global__ void k_masks_reset(FrameState *st, int n)
     if (S.status == CPE_ST_NO_REGION) { S.r0 = 0; S.spot[0] = S.spot[1] = S.spot[2] = S.spot[3] = 0; }
     else if (S.status == CPE_ST_OK && S.spot_fail) S.status = CPE_ST_NO_SPOT;
 }
-__global__ void k_spot_reset(int n, unsigned long long *best)
+__global__ void k_spot_reset(int n, unsigned long long *best, FrameState *st)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n) best[f] = 0;
+    if (f >= n) return;
+    best[f] = 0;
+    st[f].srect[0] = INT_MAX; st[f].srect[1] = INT_MAX; st[f].srect[2] = -1; st[f].srect[3] = -1;   // empty until k_spot_scan finds a tile
 }
 
 inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
@@ -1191,7 +1288,7 @@ int blur7_u8(const uint8_t *src, int n, int h, int w, const FrameState *st, uint
     Taps t7 = {{2, 7, 14, 18, 14, 7, 2}, 3, 12};
     CPE_LAUNCH_BEGIN();
     const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
-    CPE_KLAUNCH((k_blur_fused<3, BLUR_RECT>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, src, h, w, tiles_x, tiles_y, t7,
+    CPE_KLAUNCH((k_blur_fused<3>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, src, h, w, tiles_x, tiles_y, t7,
                 st, dst);
     CPE_CHECK_LAUNCH("blur7_u8");
     return CPE_OK;
@@ -1234,14 +1331,20 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
     const size_t total = (size_t)h * w * n;
     int rc;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_spot_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best_s);
+    CPE_KLAUNCH(k_spot_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best_s, st);
     Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
     {
         const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
-        CPE_KLAUNCH((k_blur_fused<9, BLUR_SPOT>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, gray, h, w, tiles_x, tiles_y,
-                    t19, (const FrameState *)st, B.g19);
+        CPE_CHECK_ARG(tiles_x <= 128 && (size_t)tiles_x * tiles_y <= (size_t)MAXROOTS * sizeof(int), "spot_stage: frame too large");
+        // tile flags: in the root list of the spot labelling, which is written after the blur has read them
+        uint8_t *flags = reinterpret_cast<uint8_t *>(B.roots_s);
+        const size_t fstride = (size_t)MAXROOTS * sizeof(int);
+        CPE_KLAUNCH(k_spot_scan, dim3((unsigned)(n * tiles_y)), dim3(256), 0, s, gray, h, w, tiles_x, tiles_y, st, flags, fstride);
+        CPE_KLAUNCH(k_blur19_spot, dim3((unsigned)(n * tiles_y)), dim3(256), 0, s, gray, h, w, tiles_x, tiles_y, t19,
+                    (const uint8_t *)flags, fstride, B.g19);
     }
-    if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab_s, B.roots_s, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 2)) != CPE_OK) return rc;
+    // labelling of blurred > 240 inside st[].srect (use_rect 3): the only place it can hold
+    if ((rc = ccl_run(B.g19, n, h, w, 240, 0, 1, B.lab_s, B.roots_s, false, nullptr, 0, nullptr, 3, nullptr, st, s, 1, 1, 2)) != CPE_OK) return rc;
     CPE_KLAUNCH(k_spot_area, dim3(4, n), dim3(64), 0, s, B.g19, h, w, B.roots_s, st, B.best_s);
     (void)hipMemsetAsync(B.cm, 255, total, s);
     CPE_KLAUNCH(k_spot_ellipse, dim3(n), dim3(64), 0, s, B.g19, n, h, w, B.best_s, st, B.verts, B.cm, planar);

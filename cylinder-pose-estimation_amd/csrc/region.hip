@@ -1639,15 +1639,40 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
         int a = (e + nh - 1) % nh;
         dev_line(out, h, w, hp[2 * a], hp[2 * a + 1], hp[2 * e], hp[2 * e + 1]);
     }
-    // scan-line fill (FillEdgeCollection): x in 16.16, left ceil / right floor, rows [ymin, ymax).
-    // 256 rows at a time: a thread finds the spans of its row (edge crossings, sorted), then the wavefronts write the rows
-    // with the lanes across x (16-byte stores where the row allows) -- one thread storing its row byte by byte, every lane
-    // on a row of its own, was most of this kernel's time.
+    // the fill is k_hull_rows' (many workgroups per frame): it reads the vertices from HBM
+    if (in_lds) {
+        int *hg = hull + (size_t)f * 4 * w;
+        for (int e = t; e < 2 * nh; e += 256) hg[e] = hp[e];
+    }
+}
+
+// scan-line fill of the hull (FillEdgeCollection): x in 16.16, left ceil / right floor, rows [ymin, ymax).  One workgroup
+// per band of HR_ROWS rows of the hull's bounding rectangle: a thread finds the spans of its row (edge crossings, sorted),
+// then the wavefronts write the rows with the lanes across x (16-byte stores where the row allows).  In round 2 the one
+// workgroup that computed the hull also filled its ~900 rows, 64 at a time per wavefront, with the rest of the CU idle.
+constexpr int HR_ROWS = 64, HR_MAXV = 1024;
+__global__ __launch_bounds__(256) void k_hull_rows(int h, int w, const unsigned long long *__restrict__ best, const FrameState *__restrict__ st,
+                                                   const int *__restrict__ hull /* n * 4 * w */, uint8_t *__restrict__ mc)
+{
+    const int f = blockIdx.y, t = threadIdx.x;
+    const FrameState &S = st[f];
+    if (best[f] == 0) return;
+    const int nh = S.hull_n;
+    if (nh <= 0) return;
     const int ymin = S.rect[1], ymax = min(S.rect[1] + S.rect[3] - 1, h);
-    __shared__ int s_span[256][8];
-    __shared__ int s_nsp[256];
+    const int yc = ymin + (int)blockIdx.x * HR_ROWS;
+    if (yc >= ymax) return;
+    __shared__ int s_hp[2 * HR_MAXV];
+    __shared__ int s_span[HR_ROWS][8];
+    __shared__ int s_nsp[HR_ROWS];
+    const int *hg = hull + (size_t)f * 4 * w;
+    const bool staged = nh <= HR_MAXV;
+    if (staged) for (int e = t; e < 2 * nh; e += 256) s_hp[e] = hg[e];
+    __syncthreads();
+    const int *hp = staged ? s_hp : hg;
+    uint8_t *out = mc + (size_t)f * h * w;
     const bool al16 = (w & 15) == 0 && (((size_t)out) & 15) == 0;
-    for (int yc = ymin; yc < ymax; yc += 256) {
+    if (t < HR_ROWS) {
         const int y = yc + t;
         int nsp = 0;
         if (y < ymax) {
@@ -1684,19 +1709,18 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
             }
         }
         s_nsp[t] = nsp;
-        __syncthreads();
-        const int lane = t & 63, wave = t >> 6;
-        for (int rr = wave; rr < 256 && yc + rr < ymax; rr += 4) {
-            uint8_t *row = out + (size_t)(yc + rr) * w;
-            for (int q = 0; q < s_nsp[rr]; q++) {
-                const int x1 = s_span[rr][2 * q], x2 = s_span[rr][2 * q + 1];
-                for (int xb = (x1 & ~15) + 16 * lane; xb <= x2; xb += 16 * 64) {
-                    if (al16 && xb >= x1 && xb + 15 <= x2) *reinterpret_cast<uint4 *>(row + xb) = make_uint4(~0u, ~0u, ~0u, ~0u);
-                    else for (int x = max(xb, x1); x <= min(xb + 15, x2); x++) row[x] = 255;
-                }
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    for (int rr = wave; rr < HR_ROWS && yc + rr < ymax; rr += 4) {
+        uint8_t *row = out + (size_t)(yc + rr) * w;
+        for (int q = 0; q < s_nsp[rr]; q++) {
+            const int x1 = s_span[rr][2 * q], x2 = s_span[rr][2 * q + 1];
+            for (int xb = (x1 & ~15) + 16 * lane; xb <= x2; xb += 16 * 64) {
+                if (al16 && xb >= x1 && xb + 15 <= x2) *reinterpret_cast<uint4 *>(row + xb) = make_uint4(~0u, ~0u, ~0u, ~0u);
+                else for (int x = max(xb, x1); x <= min(xb + 15, x2); x++) row[x] = 255;
             }
         }
-        __syncthreads();
     }
 }
 
@@ -1883,6 +1907,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if (rc != CPE_OK) return rc;
     CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best, 1);
     CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, B.mc);
+    CPE_KLAUNCH(k_hull_rows, dim3((unsigned)((h + HR_ROWS - 1) / HR_ROWS), n), dim3(256), 0, s, h, w, (const unsigned long long *)B.best, (const FrameState *)st, (const int *)B.hull, B.mc);
     CPE_CHECK_LAUNCH("region hull");
     return CPE_OK;
 }
@@ -1918,6 +1943,7 @@ int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuf
         if ((rc = build_bitplanes(img, n, h, w, thr, 0, 1, B.bits, s)) != CPE_OK) return rc;
         CPE_KLAUNCH(k_region_area, dim3(frame_waves(n, 8, 64), n), dim3(64), 0, s, (const uint32_t *)B.bits, h, w, B.roots, st, B.best, 0);
         CPE_KLAUNCH(k_hull_fill, dim3(n), dim3(256), 0, s, (const uint32_t *)B.bits, h, w, B.best, st, B.lohi, B.hull, dst);
+        CPE_KLAUNCH(k_hull_rows, dim3((unsigned)((h + HR_ROWS - 1) / HR_ROWS), n), dim3(256), 0, s, h, w, (const unsigned long long *)B.best, (const FrameState *)st, (const int *)B.hull, dst);
         if (round == 0) {
             const int tiles_x = (w + 63) / 64, tiles_y = (h + 31) / 32;
             CPE_KLAUNCH(k_dilate_ellipse, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, (const uint8_t *)B.ext, h, w, tiles_x,
