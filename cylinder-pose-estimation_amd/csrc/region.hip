@@ -1546,7 +1546,8 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
     int *lo = in_lds ? s_lo : lohi + (size_t)f * 2 * w, *hi = in_lds ? s_hi : lohi + (size_t)f * 2 * w + w;
     int *hp = in_lds ? s_hp : hull + (size_t)f * 4 * w;
     for (int x = t; x < w; x += 256) { lo[x] = INT_MAX; hi[x] = INT_MIN; }
-    __shared__ int s_box[4];
+    __shared__ int s_box[4], s_scan[4];
+    __shared__ uint8_t s_keep[2 * HULL_LDS_W + 2];
     if (t == 0) { s_box[0] = INT_MAX; s_box[1] = INT_MIN; s_box[2] = INT_MAX; s_box[3] = INT_MIN; }
     __syncthreads();
     const int ws = bit_row_words(w);
@@ -1561,26 +1562,27 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
         for (int item = t; item < nwc * SEG; item += 256) {
             const int j = item % nwc, seg = item / nwc;
             const int y0 = (int)((long long)h * seg / SEG), y1 = (int)((long long)h * (seg + 1) / SEG);
-            // rows in batches of 8: the loads of a batch are independent and in flight together
+            // rows in batches of HB: the loads of a batch are independent and in flight together
+            constexpr int HB = 16;
             uint32_t seen = 0;
-            for (int yb = y0; yb < y1; yb += 8) {
-                uint32_t v[8];
+            for (int yb = y0; yb < y1; yb += HB) {
+                uint32_t v[HB];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = yb + k < y1 ? plane[(size_t)(yb + k) * ws + 1 + j] : 0u;
+                for (int k = 0; k < HB; k++) v[k] = yb + k < y1 ? plane[(size_t)(yb + k) * ws + 1 + j] : 0u;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < HB; k++) {
                     uint32_t nw = v[k] & ~seen;
                     seen |= v[k];
                     while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMin(&lo[32 * j + b], yb + k); }
                 }
             }
             seen = 0;
-            for (int yb = y1 - 1; yb >= y0; yb -= 8) {
-                uint32_t v[8];
+            for (int yb = y1 - 1; yb >= y0; yb -= HB) {
+                uint32_t v[HB];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = yb - k >= y0 ? plane[(size_t)(yb - k) * ws + 1 + j] : 0u;
+                for (int k = 0; k < HB; k++) v[k] = yb - k >= y0 ? plane[(size_t)(yb - k) * ws + 1 + j] : 0u;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < HB; k++) {
                     uint32_t nw = v[k] & ~seen;
                     seen |= v[k];
                     while (nw) { const int b = __ffs(nw) - 1; nw &= nw - 1; atomicMax(&hi[32 * j + b], yb - k); }
@@ -1602,11 +1604,101 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
         else {
             BitWin nz{ext_bits + (size_t)f * h * ws, ws, h, s_win};
             trace_border(nz, root % w, root / w, false, hv, 8 * (w + h) + (1 << 20));
+            s_box[0] = hv.minx; s_box[1] = hv.maxx; s_box[2] = hv.miny; s_box[3] = hv.maxy;
         }
         S.rect[0] = hv.minx; S.rect[1] = hv.miny; S.rect[2] = hv.maxx - hv.minx + 1; S.rect[3] = hv.maxy - hv.miny + 1;
-        // monotone chain over columns; points sorted by (x,y): per column first lo then hi
+    }
+    __syncthreads();
+    if (in_lds) {
+        // cv2.convexHull of the contour = Andrew's monotone chain over the column extents, points sorted by (x, y): the chain from
+        // the first point to the last keeps (x, lo[x]) vertices, the chain back keeps (x, hi[x]) vertices, a point is dropped
+        // when the turn at it is not strictly convex (cross <= 0).  That chain is a serial walk (2 x ~650 columns with
+        // dependent LDS reads: most of this kernel's time in round 2).  Same vertex list, every point on its own: a point
+        // i of a chain stays iff every pair a < i < b of the chain turns strictly at it, and with u_a = P_i - P_a,
+        // v_b = P_b - P_i (all in one half plane: the points are sorted) that is cross(A, B) > 0 for the u of largest and
+        // the v of smallest direction angle -- two running maxima over the chain, exact in int32 (coordinates < 2^12).
+        int *cx = reinterpret_cast<int *>(s_win);                 // columns that hold pixels, ascending (the tracer is done with its window)
+        int *ql = s_hp, *qu = s_hp + HULL_LDS_W + 1;              // the two chains as x | y << 16
+        int *hv_out = s_hp + 2 * (HULL_LDS_W + 1);                // the vertex list (x, y pairs): 2 * (HULL_LDS_W - 1) ints
+        const int minx = s_box[0], maxx = s_box[1];
+        auto block_scan = [&](int v, int &total) {                // exclusive prefix sum over the 256 threads
+            int incl = v;
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if ((t & 63) >= off) incl += o; }
+            if ((t & 63) == 63) s_scan[t >> 6] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int k = 0; k < (t >> 6); k++) base += s_scan[k];
+            total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+            __syncthreads();
+            return base + incl - v;
+        };
+        constexpr int CPT = HULL_LDS_W / 256;                     // columns per thread
+        int cnt = 0;
+        for (int k = 0; k < CPT; k++) { const int x = minx + CPT * t + k; if (x <= maxx && lo[x] != INT_MAX) cnt++; }
+        int m;
+        int pos = block_scan(cnt, m);
+        for (int k = 0; k < CPT; k++) { const int x = minx + CPT * t + k; if (x <= maxx && lo[x] != INT_MAX) cx[pos++] = x; }
+        __syncthreads();
+        if (m <= 0) {                                               // (cannot happen for a selected component; uniform)
+            if (t == 0) { s_nh = 0; S.hull_n = 0; }
+            __syncthreads();
+            return;
+        }
+        const int xf = cx[0], xl = cx[m - 1];
+        const int mL = m + (hi[xl] != lo[xl] ? 1 : 0), mU = m + (hi[xf] != lo[xf] ? 1 : 0);
+        for (int j = t; j < mL; j += 256) { const int x = j < m ? cx[j] : xl; ql[j] = x | ((j < m ? lo[x] : hi[x]) << 16); }
+        for (int j = t; j < mU; j += 256) { const int x = j < m ? cx[m - 1 - j] : xf; qu[j] = x | ((j < m ? hi[x] : lo[x]) << 16); }
+        __syncthreads();
+        for (int idx = t; idx < mL + mU; idx += 256) {
+            const bool up = idx >= mL;
+            const int j = up ? idx - mL : idx, len = up ? mU : mL;
+            const int *q = up ? qu : ql;
+            bool keep = true;
+            if (j > 0 && j < len - 1) {
+                const int pi = q[j], xi = pi & 0xFFFF, yi = pi >> 16;
+                int ax = xi - (q[j - 1] & 0xFFFF), ay = yi - (q[j - 1] >> 16);
+                for (int a = j - 2; a >= 0; a--) {
+                    const int ux = xi - (q[a] & 0xFFFF), uy = yi - (q[a] >> 16);
+                    if (ax * uy - ay * ux > 0) { ax = ux; ay = uy; }
+                }
+                int bx = (q[j + 1] & 0xFFFF) - xi, by = (q[j + 1] >> 16) - yi;
+                for (int b = j + 2; b < len; b++) {
+                    const int vx = (q[b] & 0xFFFF) - xi, vy = (q[b] >> 16) - yi;
+                    if (vx * by - vy * bx > 0) { bx = vx; by = vy; }
+                }
+                keep = ax * by - ay * bx > 0;
+            }
+            s_keep[idx] = keep ? 1 : 0;
+        }
+        __syncthreads();
+        // vertex list: the first chain, then the second without its two end points (they are the first chain's last and first)
+        constexpr int EPT = (2 * HULL_LDS_W + 2 + 255) / 256;
+        int c2 = 0;
+        for (int k = 0; k < EPT; k++) {
+            const int idx = EPT * t + k;
+            if (idx < mL + mU && s_keep[idx] && !(idx >= mL && (idx == mL || idx == mL + mU - 1))) c2++;
+        }
+        int nv;
+        int o = block_scan(c2, nv);
+        if (m == 1 && mL == 1) nv = 0;                              // a single pixel: the chain holds one point and no polygon
+        const bool fits = nv <= HULL_LDS_W - 1;
+        for (int k = 0; k < EPT && fits; k++) {
+            const int idx = EPT * t + k;
+            if (idx < mL + mU && s_keep[idx] && !(idx >= mL && (idx == mL || idx == mL + mU - 1))) {
+                const int pv = idx >= mL ? qu[idx - mL] : ql[idx];
+                hv_out[2 * o] = pv & 0xFFFF; hv_out[2 * o + 1] = pv >> 16; o++;
+            }
+        }
+        if (t == 0) {
+            if (!fits) { set_overflow(S, OVF_VERTS); nv = 0; }
+            s_nh = nv; S.hull_n = nv;
+        }
+        hp = hv_out;
+    } else if (t == 0) {
+        // frames wider than HULL_LDS_W: the serial monotone chain over columns; points sorted by (x,y): per column first lo then hi
+        const int bminx = s_box[0], bmaxx = s_box[1];
         int k = 0;
-        for (int x = hv.minx; x <= hv.maxx; x++) {
+        for (int x = bminx; x <= bmaxx; x++) {
             if (lo[x] == INT_MAX) continue;
             int ys[2] = {lo[x], hi[x]};
             int cnt = (hi[x] != lo[x]) ? 2 : 1;
@@ -1617,7 +1709,7 @@ __global__ __launch_bounds__(256) void k_hull_fill(const uint32_t *__restrict__ 
         }
         int tmin = k + 1;
         bool first = true;
-        for (int x = hv.maxx; x >= hv.minx; x--) {
+        for (int x = bmaxx; x >= bminx; x--) {
             if (lo[x] == INT_MAX) continue;
             int ys[2] = {hi[x], lo[x]};
             int cnt = (hi[x] != lo[x]) ? 2 : 1;
