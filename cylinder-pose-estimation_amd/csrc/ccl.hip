@@ -411,6 +411,12 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
     const size_t N = (size_t)h * w;
     const size_t f = blockIdx.y;
     const int lane = threadIdx.x & 63;
+    const Rect r = get_rect(st, f, use_rect, h, w);
+    {   // the workgroup's pixels lie in rows ya .. yb: outside the working rectangle there is nothing to flatten, count or list
+        const size_t p0 = (size_t)blockIdx.x * CCL_FIN_PX;
+        const int ya = (int)(p0 / w), yb = (int)((min(p0 + CCL_FIN_PX, N) - 1) / w);
+        if (r.x1 < r.x0 || yb < r.y0 || ya > r.y1) return;
+    }
     for (int it = 0; it < CCL_FIN_PX / 256; it++) {
     const int i = blockIdx.x * CCL_FIN_PX + it * 256 + threadIdx.x;
     if ((size_t)(blockIdx.x * CCL_FIN_PX + it * 256) >= N) break;
@@ -418,7 +424,6 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const uint8_t *__restrict__ 
     int root = -1, x = 0, y = 0;
     if ((size_t)i < N) {
         y = i / w; x = i - y * w;
-        const Rect r = get_rect(st, f, use_rect, h, w);
         if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1) && (!sparse || pred(img + f * N, i, thr, invert))) {
             int v = L[gi];
             if (noflatten) {

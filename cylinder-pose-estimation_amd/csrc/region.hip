@@ -32,27 +32,46 @@ struct ClaheGeom { int tilesX, tilesY, tw, th, eh, ew, clipLimit; float lutScale
 __global__ __launch_bounds__(256) void k_clahe_hist(const uint8_t *__restrict__ gray, int n, int h, int w, ClaheGeom g,
                                                     int strips, unsigned int *__restrict__ hist, int lab_lut)
 {
-    __shared__ unsigned int sh[256];
+    // one 256-bin histogram per wavefront (the background of a frame sits in a dozen bins: with one histogram for the
+    // workgroup every LDS atomic waited for the other wavefronts' hits on the same few addresses), four pixels per load
+    __shared__ unsigned int sh[4][256];
     int b = blockIdx.x;
     int strip = b % strips; b /= strips;
     int tile = b % (g.tilesX * g.tilesY);
     int f = b / (g.tilesX * g.tilesY);
     int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
-    sh[threadIdx.x] = 0;
+    for (int k = 0; k < 4; k++) sh[k][threadIdx.x] = 0;
     __syncthreads();
+    unsigned int *mine = sh[threadIdx.x >> 6];
     const uint8_t *im = gray + (size_t)f * h * w;
     int rows_per = (g.th + strips - 1) / strips;
     int y0 = strip * rows_per, y1 = min(g.th, y0 + rows_per);
-    for (int yy = y0; yy < y1; yy++) {
-        int gy = reflect101(ty * g.th + yy, h);
-        for (int xx = threadIdx.x; xx < g.tw; xx += 256) {
-            int gx = reflect101(tx * g.tw + xx, w);
-            const int v = im[(size_t)gy * w + gx];
-            atomicAdd(&sh[lab_lut ? (int)c_lab_l[v] : v], 1u);
+    const int gx0 = tx * g.tw;
+    // the tile lies inside the frame and its rows start on dwords (frames whose size is a multiple of 4: no padding)
+    const bool fast = gx0 + g.tw <= w && ty * g.th + g.th <= h && (g.tw & 3) == 0 && (w & 3) == 0 && (((size_t)im + gx0) & 3) == 0;
+    if (fast) {
+        const int qw = g.tw >> 2;
+        for (int i = threadIdx.x; i < (y1 - y0) * qw; i += 256) {
+            const int yy = i / qw, q = i - yy * qw;
+            const uint32_t v4 = *reinterpret_cast<const uint32_t *>(im + (size_t)(ty * g.th + y0 + yy) * w + gx0 + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v = (v4 >> (8 * k)) & 255u;
+                atomicAdd(&mine[lab_lut ? (int)c_lab_l[v] : v], 1u);
+            }
+        }
+    } else {
+        for (int yy = y0; yy < y1; yy++) {
+            int gy = reflect101(ty * g.th + yy, h);
+            for (int xx = threadIdx.x; xx < g.tw; xx += 256) {
+                int gx = reflect101(gx0 + xx, w);
+                const int v = im[(size_t)gy * w + gx];
+                atomicAdd(&mine[lab_lut ? (int)c_lab_l[v] : v], 1u);
+            }
         }
     }
     __syncthreads();
-    unsigned int v = sh[threadIdx.x];
+    unsigned int v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
     if (v) atomicAdd(&hist[((size_t)f * g.tilesX * g.tilesY + tile) * 256 + threadIdx.x], v);
 }
 
@@ -136,10 +155,45 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
         if (out > 50) { mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y); }
         return out;
     };
+    // the four pixels of a dword lie in one row when the rows are a multiple of 4 long: row index, row weights and the two
+    // rows of tile tables once per dword (the per-pixel form spent a third of its instructions on i / w and the row terms)
+    auto four = [&](int i0, uint32_t v4) -> uint32_t {
+        const int y = i0 / w, x0 = i0 - y * w;
+        float tyf = y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, g.tilesY - 1);
+        const uint8_t *p1 = s_lut + (ty1 * g.tilesX) * 256, *p2 = s_lut + (ty2 * g.tilesX) * 256;
+        uint32_t o4 = 0;
+        bool any = false;
+        int xlo = INT_MAX, xhi = -1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = x0 + q;
+            float txf = x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            tx1 = max(tx1, 0);
+            tx2 = min(tx2, g.tilesX - 1);
+            const int v = s_lab[(v4 >> (8 * q)) & 255u];
+            const float a = (float)p1[tx1 * 256 + v] * xa1, b = (float)p1[tx2 * 256 + v] * xa;
+            const float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
+            const float res = (a + b) * ya1 + (c + d) * ya;
+            const int out = sat_u8((int)rintf(res));
+            if (out > 50) { any = true; xlo = min(xlo, x); xhi = max(xhi, x); }
+            o4 |= (uint32_t)out << (8 * q);
+        }
+        if (any) { mnx = min(mnx, xlo); mxx = max(mxx, xhi); mny = min(mny, y); mxy = max(mxy, y); }
+        return o4;
+    };
+    const bool row4 = al4 && (w & 3) == 0;
     for (int k = 0; k < CLAHE_BLK_PX / 1024; k++) {
         const int i0 = blockIdx.x * CLAHE_BLK_PX + k * 1024 + threadIdx.x * 4;
         if (i0 >= N) break;
-        if (al4 && i0 + 4 <= N) {
+        if (row4) {
+            *reinterpret_cast<uint32_t *>(df + i0) = four(i0, *reinterpret_cast<const uint32_t *>(gf + i0));
+        } else if (al4 && i0 + 4 <= N) {
             const uint32_t v4 = *reinterpret_cast<const uint32_t *>(gf + i0);
             uint32_t o4 = 0;
 #pragma unroll
@@ -1012,9 +1066,14 @@ __global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img
     __shared__ int s_cnt[NBK], s_base[NBK];
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int t = threadIdx.x;
+    const SwRect r = sw_rect(st, f);
+    {   // the workgroup's pixels lie in rows ya .. yb: nothing to do outside the working rectangle (three quarters of a frame)
+        const size_t p0 = (size_t)blockIdx.x * BK_CHUNK;
+        const int ya = (int)(p0 / w), yb = (int)(min(p0 + BK_CHUNK, N) - 1) / w;
+        if (r.x1 < r.x0 || yb < r.y0 || ya > r.y1) return;
+    }
     if (t < NBK) s_cnt[t] = 0;
     __syncthreads();
-    const SwRect r = sw_rect(st, f);
     const uint8_t *im = img + f * N;
     int lev[BK_CHUNK / 256];
 #pragma unroll
