@@ -8,7 +8,8 @@ The timeline is swept: at every instant the weights of the kernels in flight are
   busy        = union of kernel intervals  what share of the span had any kernel in flight
 Per kernel: calls, total ms, mean workgroups, weight, and its share of the weighted time -- the narrow kernels are the
 ones with a large 'ms' and a small 'weighted ms'.
-    python tools/occupancy.py <kernel trace csv> [skip fraction, default 0.5 = drop warm-up]"""
+    python tools/occupancy.py <kernel trace csv> [skip fraction, default 0.5 = drop warm-up] [end fraction, default 1]
+(fractions of the trace's time span: 0.52 0.9 of a `bench.py --steps 1 --warmup 1` trace lies inside the timed step)"""
 import csv
 import re
 import sys
@@ -17,6 +18,7 @@ import sys
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+    endf = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     ev = []
     for r in rows:
         wg = max(1, int(r['Workgroup_Size_X']) * int(r.get('Workgroup_Size_Y', 1) or 1) * int(r.get('Workgroup_Size_Z', 1) or 1))
@@ -27,7 +29,8 @@ def main():
     ev.sort()
     t0, t1 = ev[0][0], max(e[1] for e in ev)
     cut = t0 + (t1 - t0) * skip
-    ev = [e for e in ev if e[0] >= cut]
+    cut1 = t0 + (t1 - t0) * endf
+    ev = [e for e in ev if e[0] >= cut and e[1] <= cut1]
     t0, t1 = ev[0][0], max(e[1] for e in ev)
     pts = []
     for s, e, wt, _, _ in ev:
