@@ -30,6 +30,7 @@ _SIGS = {
     'cpe_profile_report': (C.c_int32, [C.c_char_p, C.c_size_t]),
     'cpe_preprocess_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'cpe_detect_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'cpe_detect_constants': (C.c_int32, [C.c_int32, C.c_void_p]),
     'cpe_detect_grid_batch': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t] +
                               [C.c_void_p] * 6),
     'cpe_detect_grid_batch_ex': (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t] +
@@ -63,6 +64,27 @@ _SIGS = {
 class CpeDetectParams(C.Structure):
     _fields_ = [('subpixel', C.c_int32), ('subpixel_window', C.c_int32), ('subpixel_step', C.c_double),
                 ('target', C.c_int32), ('reserved', C.c_int32)]
+
+
+class CpeDetectConstants(C.Structure):
+    """include/cpe.h: the reference's inline constants as this build was compiled with them (a report, not a setter)"""
+    _fields_ = [('blur_ksize', C.c_int32), ('hessian_sigma', C.c_double), ('sauvola_window', C.c_int32), ('sauvola_k', C.c_double),
+                ('sauvola_R', C.c_double), ('open_len', C.c_int32), ('clahe_clip', C.c_double), ('clahe_tiles', C.c_int32),
+                ('blob_thr_min', C.c_int32), ('blob_thr_step', C.c_int32), ('blob_thr_count', C.c_int32), ('blob_min_area', C.c_double),
+                ('blob_max_area', C.c_double), ('blob_min_dist', C.c_double), ('blob_min_repeat', C.c_int32),
+                ('disc_extra_radius', C.c_int32), ('spot_blur_ksize', C.c_int32), ('spot_threshold', C.c_int32),
+                ('spot_small_radius', C.c_int32), ('spot_small_add', C.c_int32), ('spot_large_add', C.c_int32), ('frag_patch', C.c_int32),
+                ('frag_min_pixels', C.c_int32), ('frag_max_pixels', C.c_int32), ('frag_kernel_base', C.c_int32),
+                ('index_blur_ksize', C.c_int32), ('poly_degree', C.c_int32), ('plane_threshold', C.c_int32),
+                ('plane_dilate_ksize', C.c_int32), ('max_points', C.c_int32), ('max_lines', C.c_int32), ('max_joints', C.c_int32),
+                ('max_groups_per_dir', C.c_int32), ('max_joints_per_group', C.c_int32)]
+
+
+def detect_constants(target='cylinder'):
+    """dict of the reference's inline constants as the kernels use them (cpe_detect_constants)"""
+    c = CpeDetectConstants()
+    check(load().cpe_detect_constants(dict(cylinder=0, plane=1)[target], C.byref(c)), 'cpe_detect_constants')
+    return {k: getattr(c, k) for k, _ in CpeDetectConstants._fields_}
 
 
 class CpeFitParams(C.Structure):

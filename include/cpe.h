@@ -113,6 +113,36 @@ CPE_API int32_t cpe_detect_grid_batch_ex(const uint8_t *gray, int32_t n, int32_t
                                          void *ws, size_t ws_bytes, double *xy, int32_t *id, int32_t *n_pts,
                                          double *center, int32_t *status, void *stream);
 
+/* The reference's inline constants, as this build was compiled with them ("Config": the reference has no
+ * configuration object -- every value below is a literal in util_cylinder.py / util_plane.py or an OpenCV default).  They are
+ * compile-time constants of the kernels (window sizes decide register windows and LDS rings), so this is a REPORT, not a
+ * setter: a maintainer who changes a literal in the reference finds here what to change in the kernels, and the tests pin the
+ * table to the reference's values.  target: CPE_TARGET_CYLINDER or CPE_TARGET_PLANE. */
+typedef struct CpeDetectConstants {
+    int32_t blur_ksize;            /* cv2.GaussianBlur(gray, (5,5), 0)                         util_cylinder.py:1790 */
+    double hessian_sigma;          /* detect_ridges(blurred, sigma=3.0)                        :1793 */
+    int32_t sauvola_window;        /* sauvola_threshold_fast(b, window_size=15, k=0.5, R=128)  :1797 */
+    double sauvola_k, sauvola_R;
+    int32_t open_len;              /* MORPH_RECT (20,1) / (1,20) openings                      :1810-1811 */
+    double clahe_clip;             /* detect_largest_blob(..., clipLimit=4.5)                  python_grid_detection_cylinder.py:88 */
+    int32_t clahe_tiles;           /* tileGridSize=(4,4) (the colour branch: the image is always 3-channel here) :1843 */
+    int32_t blob_thr_min, blob_thr_step, blob_thr_count;   /* SimpleBlobDetector defaults 50 .. 220 step 10: 17 binarisations */
+    double blob_min_area, blob_max_area;                   /* params.minArea = 10 (:1858), default maxArea 5000 */
+    double blob_min_dist;          /* default minDistBetweenBlobs 10 */
+    int32_t blob_min_repeat;       /* default minRepeatability 2 */
+    int32_t disc_extra_radius;     /* int(size / 2 + 4)                                        :1876 */
+    int32_t spot_blur_ksize;       /* cv2.GaussianBlur(gray, (19,19), 0)                       :1962 */
+    int32_t spot_threshold;        /* cv2.threshold(blurred, 240, ...)                         :1965 */
+    int32_t spot_small_radius, spot_small_add, spot_large_add;   /* radius < 30: + 20, else + 5   :1981-1984 */
+    int32_t frag_patch, frag_min_pixels, frag_max_pixels;        /* expand_line_roi(patch 15, 5 .. 200 pixels) :137 (plane: 8 .. 700) */
+    int32_t frag_kernel_base;      /* kernel_size = 91 + circle_radius0 (:2022); plane: the fixed 201 (util_plane.py:2806) */
+    int32_t index_blur_ksize;      /* cv2.GaussianBlur(img, (7,7), 0) of indexing_data         :1433 */
+    int32_t poly_degree;           /* fit_and_draw_polynomial: 2 (cylinder), 1 (plane) */
+    int32_t plane_threshold, plane_dilate_ksize;   /* get_convex_hull: threshold 127, MORPH_ELLIPSE (11,11) (util_plane.py:2590-2689); 0 for the cylinder */
+    int32_t max_points, max_lines, max_joints, max_groups_per_dir, max_joints_per_group;   /* build capacities (CPE_ST_OVERFLOW) */
+} CpeDetectConstants;
+CPE_API int32_t cpe_detect_constants(int32_t target, CpeDetectConstants *out);
+
 /* rows_updated / cols_updated of ONE frame of the last cpe_detect_grid_batch call on this workspace: the third and fourth
  * return values of detect_grid (python_grid_detection_cylinder.py:110; built by find_and_assign_intersections_P and
  * clean_and_relabel, util_cylinder.py:1106-1206).  Side 0 = rows ("row1".."rowR", ordered by mean y), side 1 = columns

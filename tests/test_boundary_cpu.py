@@ -67,3 +67,32 @@ def test_oracle_bgr2gray_fixed_point(orc):
     assert np.array_equal(S.bgr2gray(bgr), want.astype(np.uint8))
     g = rng.integers(0, 256, (5, 5), dtype=np.uint8)
     assert np.array_equal(S.bgr2gray(np.repeat(g[..., None], 3, 2)), g)               # identity on grey-replicated frames
+
+
+def test_detect_constants_report_matches_the_reference_literals(cpe):
+    """cpe_detect_constants: the inline constants of the reference as the kernels were built with them ("Config").
+    Pinned here to the values the reference's sources state; when the reference tree is present (this container only) the
+    literals are looked up in its text as well."""
+    import os
+    import re
+    c = cpe.lib.detect_constants('cylinder')
+    want = dict(blur_ksize=5, hessian_sigma=3.0, sauvola_window=15, sauvola_k=0.5, sauvola_R=128.0, open_len=20, clahe_clip=4.5,
+                clahe_tiles=4, blob_thr_min=50, blob_thr_step=10, blob_thr_count=17, blob_min_area=10.0, blob_max_area=5000.0,
+                blob_min_dist=10.0, blob_min_repeat=2, disc_extra_radius=4, spot_blur_ksize=19, spot_threshold=240,
+                spot_small_radius=30, spot_small_add=20, spot_large_add=5, frag_patch=15, frag_min_pixels=5, frag_max_pixels=200,
+                frag_kernel_base=91, index_blur_ksize=7, poly_degree=2, plane_threshold=0, plane_dilate_ksize=0)
+    for k, v in want.items():
+        assert c[k] == v, (k, c[k], v)
+    p = cpe.lib.detect_constants('plane')
+    assert (p['frag_kernel_base'], p['frag_min_pixels'], p['frag_max_pixels'], p['poly_degree'], p['plane_threshold'],
+            p['plane_dilate_ksize'], p['blob_thr_count']) == (201, 8, 700, 1, 127, 11, 0)
+    assert (c['max_points'], c['max_lines'], c['max_joints'], c['max_joints_per_group']) == (2048, 256, 16384, 1024)
+    src = '/root/reference/utils/util_cylinder.py'
+    if os.path.exists(src):
+        text = open(src, encoding='utf-8').read()
+        for pat in (r'GaussianBlur\(gray_img, \(5, 5\), 0\)', r'detect_ridges\(blurred_img, sigma=3\.0\)',
+                    r'sauvola_threshold_fast\(b, window_size=15, k=0\.5, R=128\)', r'MORPH_RECT, \(20, 1\)', r'tileGridSize=\(4,4\)',
+                    r'params\.minArea = 10', r'int\(radius \+ 4\)', r'GaussianBlur\(image_gray, \(19, 19\), 0\)',
+                    r'threshold\(blurred, 240, 240', r'if circle_radius < 30:', r'kernel_size=\(91 \+ circle_radius0\)',
+                    r'min_pixels=5, max_pixels=200', r'GaussianBlur\(input_image, \(7, 7\), 0\)'):
+            assert re.search(pat, text), pat
