@@ -153,40 +153,41 @@ __device__ __forceinline__ int window_x0(const FrameState &S, int use_rect)
 }
 
 // ---------------------------------------------------------------- union-find on an int label plane
-__device__ __forceinline__ int uf_load(const int *L, int i)
+// S: ints per node (1: a plain label plane; 2: the bright forest of the blob sweep, whose node is {parent, merge-history word})
+template <int S = 1> __device__ __forceinline__ int uf_load(const int *L, int i)
 {
-    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(L + (size_t)i * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ int uf_find(const int *L, int x)
+template <int S = 1> __device__ __forceinline__ int uf_find(const int *L, int x)
 {
     int p;
-    while ((p = uf_load(L, x)) != x) x = p;
+    while ((p = uf_load<S>(L, x)) != x) x = p;
     return x;
 }
 // find with intermediate pointer jumping (ECL-CC): every node on the walked path is re-pointed at its
 // grandparent.  Parents always have smaller indices and roots are never written, so concurrent use with
 // uf_unite is safe; stale writes can only re-point a node at another of its ancestors.
-__device__ __forceinline__ int uf_find_c(int *L, int x)
+template <int S = 1> __device__ __forceinline__ int uf_find_c(int *L, int x)
 {
-    int curr = uf_load(L, x);
+    int curr = uf_load<S>(L, x);
     if (curr != x) {
         int prev = x, next;
-        while (curr > (next = uf_load(L, curr))) {
-            __hip_atomic_store(L + prev, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (curr > (next = uf_load<S>(L, curr))) {
+            __hip_atomic_store(L + (size_t)prev * S, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             prev = curr;
             curr = next;
         }
     }
     return curr;
 }
-__device__ __forceinline__ void uf_unite(int *L, int a, int b)
+template <int S = 1> __device__ __forceinline__ void uf_unite(int *L, int a, int b)
 {
     for (;;) {
-        a = uf_find_c(L, a);
-        b = uf_find_c(L, b);
+        a = uf_find_c<S>(L, a);
+        b = uf_find_c<S>(L, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
-        int old = atomicMin(&L[a], b);
+        int old = atomicMin(&L[(size_t)a * S], b);
         if (old == a) return;
         a = old;
     }

@@ -83,7 +83,7 @@ Layout make_layout(int n, int h, int w)
     per[P_HULL] = (size_t)4 * w * sizeof(int);
     per[P_LINES] = lines_ws_bytes();
     per[P_NRECT] = 16 * sizeof(int);
-    per[P_LAB2] = N * 4;
+    per[P_LAB2] = N * 8;   // the bright forest of the blob sweep: {parent, merge-history word} per pixel
     per[P_LAB3] = N * 4;
     per[P_SW] = 192 * sizeof(int);
     per[P_TL] = (size_t)sweep_pool(h, w, SWL_TRACE) * sizeof(int2);
@@ -93,8 +93,8 @@ Layout make_layout(int n, int h, int w)
     per[P_ROOTSP] = (size_t)MAXROOTS * sizeof(int);
     per[P_ROOTSS] = (size_t)MAXROOTS * sizeof(int);
     per[P_BEST2] = sizeof(unsigned long long);
-    per[P_HPAR] = N * 4;
-    per[P_HTIME] = N;
+    per[P_HPAR] = 16;      // (unused: the merge history lives in the bright forest's nodes)
+    per[P_HTIME] = 16;
     per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 4 * sizeof(double);   // x, y, r, next group in the grid cell
     per[P_FLJ] = (size_t)2 * h * ((w + 63) / 64) * sizeof(unsigned long long);   // joints chain: background / outer-background bit masks
     per[P_BITS] = (size_t)17 * h * bit_row_words(w) * sizeof(uint32_t);

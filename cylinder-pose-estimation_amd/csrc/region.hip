@@ -1015,13 +1015,12 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
 // the accumulator plane only between the two barriers of a threshold (atomics both ways: no stale L1 lines).
 #define ENC_NT 1024
 __global__ __launch_bounds__(ENC_NT) void k_enclosed_all(const int2 *__restrict__ hl, int2 *__restrict__ bl, const int *__restrict__ sw,
-                                                         const int *__restrict__ hpar, const uint8_t *__restrict__ htime,
+                                                         const int *__restrict__ forest /* bright: {parent, history} per pixel */,
                                                          int h, int w, int *__restrict__ encl)
 {
     const size_t N = (size_t)h * w, f = blockIdx.x;
     const int *S = sw + f * SW_STRIDE;
-    const int *hp = hpar + f * N;
-    const uint8_t *ht = htime + f * N;
+    const unsigned *hist = reinterpret_cast<const unsigned *>(forest) + f * N * 2 + 1;   // hist[2 c]: (absorbing root) | (step << 24)
     int *ef = encl + f * N;
     const int pool_h = sweep_pool(h, w, SWL_DARK), pool_l = sweep_pool(h, w, SWL_BRIGHT);
     for (int slot = 0; slot < NTHR; slot++) {
@@ -1031,7 +1030,7 @@ __global__ __launch_bounds__(ENC_NT) void k_enclosed_all(const int2 *__restrict_
         for (int k = threadIdx.x; k < nh; k += ENC_NT) {
             const int2 e = hl[f * pool_h + sh.off + k];
             int c = e.x - 1;                               // bright pixel west of the hole
-            while ((int)ht[c] <= t) c = hp[c];
+            for (unsigned hv; (int)((hv = hist[2 * (size_t)c]) >> 24) <= t;) c = (int)(hv & 0xFFFFFFu);
             atomicAdd(&ef[c], min(e.y, 5000));
         }
         __syncthreads();
@@ -1154,7 +1153,8 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint32_t *
     const size_t plane_words = (size_t)h * ws;
     const uint32_t *bm = bits + (f * NTHR + pm) * plane_words;
     const uint32_t *bo = bits + (f * NTHR + (po < 0 ? pm : po)) * plane_words;
-    int *Pf = P + f * N;
+    constexpr int FS = DARK ? 1 : 2;              // ints per forest node (the bright forest: {parent, merge-history word})
+    int *Pf = P + f * N * FS;
     // A pair of adjacent members is united by the newer pixel (the later one in raster order when both are new).
     // Horizontal pairs always; a vertical pair only if the pair one column to the left is not also a member pair
     // (that pair is connected by induction and joins through the two horizontal links); a diagonal pair only if
@@ -1204,7 +1204,7 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint32_t *
         int mine = INT_MAX;
 #pragma unroll
         for (int k = 0; k < (DARK ? 4 : 8); k++)
-            if (k < np) { pr[k] = uf_find(Pf, pr[k]); mine = min(mine, pr[k]); }   // read-only walk: k_sw_new flattens every step, the paths are short, and pointer-jumping stores are fabric writes
+            if (k < np) { pr[k] = uf_find<FS>(Pf, pr[k]); mine = min(mine, pr[k]); }   // read-only walk: k_sw_new flattens every step, the paths are short, and pointer-jumping stores are fabric writes
         // smallest partner root of the run: segmented min over the lanes that share a first lane
         const unsigned long long starts = __ballot(i >= 0 && !prel);
         const int hl = i >= 0 ? 63 - __clzll((long long)(starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)))) : -1 - lane;
@@ -1216,10 +1216,10 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint32_t *
         }
         const int runmin = __shfl(m, hl < 0 ? lane : hl, 64);
         if (i >= 0 && runmin != INT_MAX) {
-            if (lane == hl) uf_unite(Pf, i, runmin);
+            if (lane == hl) uf_unite<FS>(Pf, i, runmin);
 #pragma unroll
             for (int k = 0; k < (DARK ? 4 : 8); k++)
-                if (k < np && pr[k] != runmin) uf_unite(Pf, pr[k], runmin);   // the run joins several components: rare
+                if (k < np && pr[k] != runmin) uf_unite<FS>(Pf, pr[k], runmin);   // the run joins several components: rare
         }
     }
 }
@@ -1270,15 +1270,19 @@ template <bool DARK>
 __device__ __forceinline__ void sw_new_body(const SwBlock vb, int h, int w, int bucket, int init_bucket, FrameState *__restrict__ st,
                                             const int *__restrict__ bk, int *__restrict__ P, int *__restrict__ acc,
                                             const uint8_t *__restrict__ touch, int epoch, int2 *__restrict__ lists,
-                                            int *__restrict__ sw, int cnt_base, int slot,
-                                            int *__restrict__ hpar, uint8_t *__restrict__ htime)
+                                            int *__restrict__ sw, int cnt_base, int slot)
 {
+    // The bright forest's node is {parent, history word}: history = (root that absorbed the entry) | (step << 24), 0xFFFFFFFF
+    // while the entry has never been absorbed -- what k_enclosed_all follows to read the forest as it was at an earlier
+    // step.  One 8-byte store per new pixel where round 2 wrote three planes (parent, absorbing root, step), and the
+    // "never" value comes with the entry's first store instead of a memset of a plane.
     const size_t N = (size_t)h * w, f = vb.f;
     const int lane = threadIdx.x & 63;
     const int *S = sw + f * SW_STRIDE;
     const int nb = S[SW_BS + bucket];
     const int *list = bk + f * N + S[SW_BO + bucket];
-    int *Pf = P + f * N;
+    constexpr int FS = DARK ? 1 : 2;
+    int *Pf = P + f * N * FS;
     if (init_bucket >= 1 && init_bucket < NBK) {
         // The pixels that join at the next step get their first entry now (nothing reads it before that).  Bucket lists
         // are in raster order, so neighbouring lanes mostly hold neighbouring pixels of a row: such a run is linked to its
@@ -1293,7 +1297,9 @@ __device__ __forceinline__ void sw_new_body(const SwBlock vb, int h, int w, int 
             const unsigned long long starts = __ballot(p >= 0 && !linked);
             if (p >= 0) {
                 const unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-                Pf[p] = p - (lane - (63 - __clzll(m)));
+                const int first = p - (lane - (63 - __clzll(m)));
+                if (DARK) Pf[p] = first;
+                else *reinterpret_cast<int2 *>(Pf + 2 * (size_t)p) = make_int2(first, -1);
             }
         }
     }
@@ -1306,10 +1312,10 @@ __device__ __forceinline__ void sw_new_body(const SwBlock vb, int h, int w, int 
         int i = -1, root = -1;
         if (isnew) {
             i = list[e];
-            root = uf_find(Pf, i);
+            root = uf_find<FS>(Pf, i);
             if (root != i) {
-                Pf[i] = root;
-                if (!DARK) { hpar[f * N + i] = root; htime[f * N + i] = (uint8_t)epoch; }   // joined `root` at this step
+                if (DARK) Pf[i] = root;
+                else *reinterpret_cast<int2 *>(Pf + 2 * (size_t)i) = make_int2(root, root | (epoch << 24));   // joined `root` at this step
             }
         }
         bool is_root = isnew && root == i;
@@ -1336,8 +1342,7 @@ __device__ __forceinline__ void sw_old_body(const SwBlock vb, const int *__restr
                                             const int *__restrict__ src_cnt, int src_cnt_stride, int src_slot,
                                             int h, int w, FrameState *__restrict__ st, int *__restrict__ P,
                                             int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
-                                            int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
-                                            int *__restrict__ hpar, uint8_t *__restrict__ htime)
+                                            int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot)
 {
     // source: the list of threshold `src_slot` (the previous step) or, for the first dark step (src_slot < 0), the root list
     // of the run-based labelling (src: ints, src_frame_stride apart, src_cnt[f * src_cnt_stride] of them)
@@ -1357,16 +1362,17 @@ __device__ __forceinline__ void sw_old_body(const SwBlock vb, const int *__restr
     int r = 0;
     if (k < ns) {
         r = sp[(size_t)k * es];
-        int *Pf = P + f * N;
+        constexpr int FS = DARK ? 1 : 2;
+        int *Pf = P + f * N * FS;
         if (DARK) {
             if (touch[f * N + r] != (uint8_t)epoch) {
                 if (uf_load(Pf, r) == r) keep = true;
                 else atomicAdd(&acc[f * N + uf_find_c(Pf, r)], acc[f * N + r]);
             }
         } else {
-            keep = uf_load(Pf, r) == r;
+            keep = uf_load<FS>(Pf, r) == r;
             if (keep) acc[f * N + r] = 0;
-            else { hpar[f * N + r] = uf_find_c(Pf, r); htime[f * N + r] = (uint8_t)epoch; }   // absorbed at this step
+            else Pf[2 * (size_t)r + 1] = uf_find_c<FS>(Pf, r) | (epoch << 24);   // absorbed at this step
         }
     }
     sw_append(keep, r, &sw[f * SW_STRIDE + cnt_base + slot], lists + f * (size_t)pool + loff, &st[f], pool - loff);
@@ -1442,7 +1448,6 @@ __global__ __launch_bounds__(256) void k_sw_new_old(int n, int g_new, int g_old,
                                                     FrameState *__restrict__ st, const int *__restrict__ bk, int *__restrict__ P,
                                                     int *__restrict__ acc, const uint8_t *__restrict__ touch, int epoch,
                                                     int2 *__restrict__ lists, int *__restrict__ sw, int cnt_base, int slot,
-                                                    int *__restrict__ hpar, uint8_t *__restrict__ htime,
                                                     const int *__restrict__ src, size_t src_frame_stride, int src_cap,
                                                     const int *__restrict__ src_cnt, int src_cnt_stride, int src_slot)
 {
@@ -1450,11 +1455,11 @@ __global__ __launch_bounds__(256) void k_sw_new_old(int n, int g_new, int g_old,
     if (vb.f < 0) return;
     if (vb.bx < g_new) {
         vb.gx = g_new;
-        sw_new_body<DARK>(vb, h, w, bucket, init_bucket, st, bk, P, acc, touch, epoch, lists, sw, cnt_base, slot, hpar, htime);
+        sw_new_body<DARK>(vb, h, w, bucket, init_bucket, st, bk, P, acc, touch, epoch, lists, sw, cnt_base, slot);
     } else {
         vb.bx -= g_new; vb.gx = g_old;
         sw_old_body<DARK>(vb, src, src_frame_stride, src_cap, src_cnt, src_cnt_stride, src_slot, h, w, st, P, acc, touch, epoch,
-                          lists, sw, cnt_base, slot, hpar, htime);
+                          lists, sw, cnt_base, slot);
     }
 }
 
@@ -1992,8 +1997,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             // first entries of the pixels that join at the next step (bucket 1) | the roots of the labelling that are holes
             CPE_KLAUNCH(k_sw_new_old<true>, dim3(sw_grid(n_grid, g_bk + g_roots)), dim3(256), 0, ds, nx, g_bk, g_roots, h, w, 0, 1, st,
-                        (const int *)B.bk, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr,
-                        (uint8_t *)nullptr, (const int *)B.roots, (size_t)MAXROOTS, (int)MAXROOTS, (const int *)&st[0].n_roots,
+                        (const int *)B.bk, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (const int *)B.roots, (size_t)MAXROOTS, (int)MAXROOTS, (const int *)&st[0].n_roots,
                         (int)(sizeof(FrameState) / sizeof(int)), -1);
         } else {
             // unions of the pixels that join at this threshold | totals of the previous threshold frozen
@@ -2003,8 +2007,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
             CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             CPE_KLAUNCH(k_sw_new_old<true>, dim3(sw_grid(n_grid, g_bk + g_list)), dim3(256), 0, ds, nx, g_bk, g_list, h, w, k, k + 1 < NTHR ? k + 1 : 0, st,
-                        (const int *)B.bk, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (int *)nullptr,
-                        (uint8_t *)nullptr, (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, k - 1);
+                        (const int *)B.bk, B.lab, B.cnt, (const uint8_t *)B.touch, epoch, B.hl, B.sw, (int)SW_NH, k, (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, k - 1);
         }
         CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
@@ -2020,10 +2023,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
     // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
-    (void)hipMemsetAsync(B.htime, 0xFF, total, s);
     if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
     CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
-                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0, B.hpar, B.htime,
+                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0,
                 (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, 0);
     for (int j = 0; j < NTHR; j++) {
         const int k = NTHR - 1 - j;   // members: v > 50 + 10 k (plane k); members before this step: v > 60 + 10 k (plane k + 1; none at j = 0)
@@ -2031,13 +2033,13 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
                     (const FrameState *)st, (const int *)B.bk, B.lab2, (int2 *)nullptr, B.sw, 0, 0, (const int *)nullptr, (int2 *)nullptr, st);
         const int go = j > 0 ? g_list : 0;   // survivors of the previous (higher) threshold
         CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk + go)), dim3(256), 0, s, nx, g_bk, go, h, w, k + 1, k, st, (const int *)B.bk, B.lab2, B.cnt2,
-                    (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k, B.hpar, B.htime,
+                    (const uint8_t *)nullptr, j, B.bl, B.sw, (int)SW_NL, k,
                     (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, k + 1);
         CPE_CHECK_LAUNCH("blob sweep (bright)");
     }
     if (side) (void)hipStreamWaitEvent(s, side->medians, 0);
-    CPE_KLAUNCH(k_enclosed_all, dim3(n), dim3(ENC_NT), 0, s, (const int2 *)B.hl, B.bl, (const int *)B.sw, (const int *)B.hpar,
-                (const uint8_t *)B.htime, h, w, B.cnt2);
+    CPE_KLAUNCH(k_enclosed_all, dim3(n), dim3(ENC_NT), 0, s, (const int2 *)B.hl, B.bl, (const int *)B.sw, (const int *)B.lab2,
+                h, w, B.cnt2);
     CPE_KLAUNCH(k_blob_trace<0>, gtrace, dim3(64), 0, s, (const uint8_t *)B.cl, h, w, (const int2 *)B.bl, (int)SW_NL, st, B.sw, B.blobs,
                 B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
     CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 8, 32), n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
