@@ -65,13 +65,26 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint8_t *__restrict__ im
         unsigned long long prev = (b << 1) | (unsigned long long)carry_in;
         unsigned long long starts = b & ~prev;
         if (cnt && valid) cnt[base + x] = 0;
+        // sparse 3: first node of a pixel outside the set = the first pixel of its run of one grey-level bucket inside this
+        // 64-pixel chunk (the run joins the dark forest of the blob sweep as one component; depth 1, like the run labels above)
+        int pre = -1;
+        if (sparse == 3) {
+            const int lv = (valid && !in) ? sweep_level(img[base + x]) : 0;
+            const int lvl_left = __shfl_up(lv, 1, 64);
+            const bool same = lv > 0 && lane > 0 && lvl_left == lv;
+            const unsigned long long st3 = __ballot(lv > 0 && !same);
+            if (lv > 0) pre = y * w + x - (lane - (63 - __clzll((long long)(st3 & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))))));
+        }
         if (in) {
             unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
             int sx = m ? (x0 + 63 - __clzll(m)) : carry_start;
             L[base + x] = y * w + sx;
         } else if (valid && sparse != 1) {
-            // sparse 1: labels outside the set are never read; 2: singletons (a growing set will absorb them later)
-            L[base + x] = sparse ? y * w + x : -1;
+            // sparse 1: labels outside the set are never read; 2: singletons (a growing set will absorb them later);
+            // 3 (the dark forest of the blob sweep): singletons, except that the pixels of a run that joins the set at one
+            // threshold (same grey-level bucket) start as children of the run's first pixel -- the run is one component the
+            // moment it joins, and these stores are coalesced, which the per-bucket lists' are not
+            L[base + x] = pre >= 0 ? pre : (sparse ? y * w + x : -1);
         }
         bool last_in = (b >> 63) & 1ull;
         if (last_in) {

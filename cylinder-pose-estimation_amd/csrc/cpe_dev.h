@@ -152,6 +152,10 @@ __device__ __forceinline__ int window_x0(const FrameState &S, int use_rect)
     return use_rect == 2 ? max(S.rect[0] - 2, 0) : (use_rect == 1 ? S.crect[0] : 0);
 }
 
+// grey-level bucket of a CLAHE value for the blob sweep: 0: v <= 50 (dark at every threshold), b: 50 + 10 (b - 1) < v <= 50 + 10 b,
+// 17: v > 210.  Bucket b joins the dark forest at threshold slot b and the bright forest at slot b - 1.
+__host__ __device__ inline int sweep_level(int v) { return v <= 50 ? 0 : (((v - 41) / 10) < 17 ? ((v - 41) / 10) : 17); }
+
 // ---------------------------------------------------------------- union-find on an int label plane
 // S: ints per node (1: a plain label plane; 2: the bright forest of the blob sweep, whose node is {parent, merge-history word})
 template <int S = 1> __device__ __forceinline__ int uf_load(const int *L, int i)

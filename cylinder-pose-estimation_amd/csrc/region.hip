@@ -1055,12 +1055,17 @@ __device__ __forceinline__ SwRect sw_rect(const FrameState *st, size_t f)
 
 // ---- pixels of the rectangle sorted by the step at which they join: bucket b is new for the dark set at threshold
 // slot b and for the bright set at slot b - 1, so every later kernel of the sweep runs over a dense list
-__device__ __forceinline__ int sw_level(int v) { return v <= 50 ? 0 : min(NTHR, (v - 41) / 10); }
+__device__ __forceinline__ int sw_level(int v) { return sweep_level(v); }
+static_assert(NTHR == 17, "sweep_level (cpe_dev.h) holds the bucket count");
 constexpr int BK_CHUNK = 8192;    // pixels per workgroup of the two bucket passes
 
+// The scatter pass also gives every listed pixel its first node of the bright forest: {the first pixel of its run of one
+// bucket inside the wavefront's 64 pixels, never absorbed}.  (Round 2 wrote these entries bucket by bucket, one step ahead
+// of their use, through the lists: 2 % of the rectangle per pass, one 64-byte line per entry; here the stores of a
+// wavefront fall into a few lines.)
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img, int h, int w, const FrameState *__restrict__ st,
-                                                 int *__restrict__ sw, int *__restrict__ bk)
+                                                 int *__restrict__ sw, int *__restrict__ bk, int *__restrict__ bright /* nodes {parent, history} */)
 {
     __shared__ int s_cnt[NBK], s_base[NBK];
     const size_t N = (size_t)h * w, f = blockIdx.y;
@@ -1078,10 +1083,22 @@ __global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img
 #pragma unroll
     for (int k = 0; k < BK_CHUNK / 256; k++) {
         const size_t i = (size_t)blockIdx.x * BK_CHUNK + k * 256 + t;
-        int l = 0;
+        int l = 0, x = 0;
         if (i < N) {
-            const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+            const int y = (int)(i / w);
+            x = (int)(i - (size_t)y * w);
             if (!(y < r.y0 || y > r.y1 || x < r.x0 || x > r.x1)) l = sw_level(im[i]);
+        }
+        if (SCATTER) {
+            // first node of the bright forest: the first pixel of the pixel's run of one bucket among this wavefront's 64
+            // consecutive pixels (depth 1; x > r.x0: the lane before holds the left neighbour in the same row)
+            const int lane = t & 63, ll = __shfl_up(l, 1, 64);
+            const bool same = l > 0 && lane > 0 && ll == l && x > r.x0;
+            const unsigned long long st1 = __ballot(l > 0 && !same);
+            if (l > 0) {
+                const int first = (int)i - (lane - (63 - __clzll((long long)(st1 & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))))));
+                *reinterpret_cast<int2 *>(bright + (f * N + i) * 2) = make_int2(first, -1);
+            }
         }
         lev[k] = l;
         if (l && !SCATTER) atomicAdd(&s_cnt[l], 1);
@@ -1167,7 +1184,10 @@ __device__ __forceinline__ void sw_unite_body(const SwBlock vb, const uint32_t *
     for (int e0 = vb.bx * 256; e0 < nb; e0 += vb.gx * 256) {   // wave-uniform: the shuffles below need every lane
         const int e = e0 + threadIdx.x;
         const int i = e < nb ? list[e] : -2;
-        const bool prel = sw_prelinked(i, w, lane);   // already points at its run's first pixel (k_sw_new, init pass)
+        // already a child of its run's first pixel: the previous entry is its left neighbour AND the passes that wrote the first
+        // nodes saw the two in one 64-pixel chunk (k_ccl_init: chunks from the rectangle's left edge; k_bk_pass: 64 consecutive
+        // frame indices) -- runs are not linked across chunk borders, there the pixel unites with its left neighbour below
+        const bool prel = sw_prelinked(i, w, lane) && (DARK ? (((i % w) - r.x0) & 63) != 0 : (i & 63) != 0);
         int pr[DARK ? 4 : 8], np = 0;
         if (i >= 0) {
             const int y = i / w, x = i - y * w;
@@ -1283,26 +1303,9 @@ __device__ __forceinline__ void sw_new_body(const SwBlock vb, int h, int w, int 
     const int *list = bk + f * N + S[SW_BO + bucket];
     constexpr int FS = DARK ? 1 : 2;
     int *Pf = P + f * N * FS;
-    if (init_bucket >= 1 && init_bucket < NBK) {
-        // The pixels that join at the next step get their first entry now (nothing reads it before that).  Bucket lists
-        // are in raster order, so neighbouring lanes mostly hold neighbouring pixels of a row: such a run is linked to its
-        // first pixel right here, with plain stores, and k_sw_unite (same lane <-> entry mapping, see sw_prelinked) skips
-        // the union with the left neighbour for them -- about half of all unions, each a memory-side atomic.
-        const int ni = S[SW_BS + init_bucket];
-        const int *li = bk + f * N + S[SW_BO + init_bucket];
-        for (int e0 = vb.bx * 256; e0 < ni; e0 += vb.gx * 256) {
-            const int e = e0 + threadIdx.x;
-            const int p = e < ni ? li[e] : -2;
-            const bool linked = sw_prelinked(p, w, lane);
-            const unsigned long long starts = __ballot(p >= 0 && !linked);
-            if (p >= 0) {
-                const unsigned long long m = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-                const int first = p - (lane - (63 - __clzll(m)));
-                if (DARK) Pf[p] = first;
-                else *reinterpret_cast<int2 *>(Pf + 2 * (size_t)p) = make_int2(first, -1);
-            }
-        }
-    }
+    // (the entries' first nodes -- singletons, runs of one bucket pre-linked along the row -- come from the passes that stream
+    //  the image: k_ccl_init for the dark forest, k_bk_pass for the bright one)
+    (void)init_bucket;
     if (bucket < 1) return;
     const int pool = sweep_pool(h, w, DARK ? SWL_DARK : SWL_BRIGHT);
     const int loff = sw_slot(S, cnt_base, slot, !DARK, pool).off;   // the counters of the other thresholds are at rest
@@ -1976,9 +1979,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
-        CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
+        CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk, (int *)nullptr);
         CPE_KLAUNCH(k_bk_scan, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
-        CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk);
+        CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk, B.lab2);
         CPE_CHECK_LAUNCH("grey-level buckets");
     }
     // the dark sweep and the hole borders run on the helper stream (if any) beside the bright sweep: the two forests
@@ -1992,7 +1995,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         const int thr = 50 + 10 * k, epoch = k + 1;
         if (k == 0) {
             // the bulk of the dark set: run-based labelling, flattened; pixels outside it start as singletons
-            if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 2)) != CPE_OK) return rc;
+            if ((rc = ccl_run(B.cl, n, h, w, thr, 1, 0, B.lab, B.roots, false, nullptr, 1, B.cnt, 1, nullptr, st, ds, 3)) != CPE_OK) return rc;   // sparse 3: + the sweep's pre-linked runs
             CPE_KLAUNCH(k_sw_touch, dim3(frame_waves(4 * n, 2, 8), n), dim3(256), 0, ds, (const uint8_t *)B.cl, n, h, w, thr,
                         (const FrameState *)st, (const int *)B.lab, B.touch, epoch);
             // first entries of the pixels that join at the next step (bucket 1) | the roots of the labelling that are holes
@@ -2022,11 +2025,8 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         if (side) (void)hipEventRecord(side->medians, ds);
     }
     // ---- descending thresholds: bright components (8-conn); B.bl[k] = (first pixel, pixels of the holes it encloses)
-    // the bright forest's entries are made singletons bucket by bucket, one step ahead of their use (first: bucket 17)
+    // (the bright forest's first nodes were written by k_bk_pass)
     if (side) (void)hipStreamWaitEvent(s, side->traced, 0);
-    CPE_KLAUNCH(k_sw_new_old<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, h, w, 0, (int)NTHR, st, (const int *)B.bk, B.lab2, B.cnt2,
-                (const uint8_t *)nullptr, 0, B.bl, B.sw, (int)SW_NL, 0,
-                (const int *)nullptr, (size_t)0, 0, (const int *)nullptr, 0, 0);
     for (int j = 0; j < NTHR; j++) {
         const int k = NTHR - 1 - j;   // members: v > 50 + 10 k (plane k); members before this step: v > 60 + 10 k (plane k + 1; none at j = 0)
         CPE_KLAUNCH(k_sw_unite_snap<false>, dim3(sw_grid(n_grid, g_bk)), dim3(256), 0, s, nx, g_bk, 0, (const uint32_t *)B.bits, k, j == 0 ? -1 : k + 1, h, w, k + 1,
