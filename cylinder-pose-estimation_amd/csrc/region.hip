@@ -112,11 +112,17 @@ __global__ __launch_bounds__(256) void k_clahe_lut(unsigned int *__restrict__ hi
 // (the lowest threshold of the blob detector) in nrect[f]: the working rectangle of the whole sweep comes with the pass
 // that writes the image.  (Many pixels per workgroup keep the same-address atomics on the box rare.)
 constexpr int CLAHE_BLK_PX = 8192;
+// bucket_cnt (optional): the sweep's grey-level bucket sizes (sw + SW_BS, SW_STRIDE ints per frame) are counted here as well:
+// every pixel above the lowest threshold lies inside the working rectangle by the rectangle's definition, so the counting
+// pass of the bucket sort (one more read of the image) is not needed.
 __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ gray, int h, int w,
                                                      ClaheGeom g, const uint8_t *__restrict__ lut,
-                                                     uint8_t *__restrict__ dst, int *__restrict__ nrect, int lab_lut)
+                                                     uint8_t *__restrict__ dst, int *__restrict__ nrect, int lab_lut,
+                                                     int *__restrict__ bucket_cnt, int bucket_stride)
 {
     __shared__ int s_b[4];
+    __shared__ int s_lv[32];
+    if (threadIdx.x < 32) s_lv[threadIdx.x] = 0;
     __shared__ uint8_t s_lut[16 * 256];
     __shared__ uint8_t s_lab[256];
     const int N = h * w;
@@ -152,7 +158,10 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
         float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
         float res = (a + b) * ya1 + (c + d) * ya;
         const int out = sat_u8((int)rintf(res));
-        if (out > 50) { mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y); }
+        if (out > 50) {
+            mnx = min(mnx, x); mxx = max(mxx, x); mny = min(mny, y); mxy = max(mxy, y);
+            if (bucket_cnt) atomicAdd(&s_lv[sweep_level(out)], 1);
+        }
         return out;
     };
     // the four pixels of a dword lie in one row when the rows are a multiple of 4 long: row index, row weights and the two
@@ -181,7 +190,10 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
             const float c = (float)p2[tx1 * 256 + v] * xa1, d = (float)p2[tx2 * 256 + v] * xa;
             const float res = (a + b) * ya1 + (c + d) * ya;
             const int out = sat_u8((int)rintf(res));
-            if (out > 50) { any = true; xlo = min(xlo, x); xhi = max(xhi, x); }
+            if (out > 50) {
+                any = true; xlo = min(xlo, x); xhi = max(xhi, x);
+                if (bucket_cnt) atomicAdd(&s_lv[sweep_level(out)], 1);
+            }
             o4 |= (uint32_t)out << (8 * q);
         }
         if (any) { mnx = min(mnx, xlo); mxx = max(mxx, xhi); mny = min(mny, y); mxy = max(mxy, y); }
@@ -213,6 +225,8 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
         }
     }
     __syncthreads();
+    if (bucket_cnt && threadIdx.x > 0 && threadIdx.x < 32 && s_lv[threadIdx.x])
+        atomicAdd(&bucket_cnt[f * bucket_stride + threadIdx.x], s_lv[threadIdx.x]);
     if (threadIdx.x == 0 && s_b[2] >= 0) {
         int *nr = nrect + 16 * f;   // test first: most workgroups lie inside the box already
         if (s_b[0] < __hip_atomic_load(nr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(nr + 0, s_b[0]);
@@ -1961,7 +1975,9 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     const int strips = 8;
     CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist, lab_lut);
     CPE_KLAUNCH(k_clahe_lut, dim3(n * 16), dim3(256), 0, s, B.hist, g, B.lut);
-    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + CLAHE_BLK_PX - 1) / CLAHE_BLK_PX), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect, lab_lut);
+    (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);   // the sweep's counters: k_clahe_apply already counts the buckets
+    CPE_KLAUNCH(k_clahe_apply, dim3((unsigned)((N + CLAHE_BLK_PX - 1) / CLAHE_BLK_PX), n), dim3(256), 0, s, gray, h, w, g, (const uint8_t *)B.lut, B.cl, B.nrect, lab_lut,
+                B.sw + SW_BS, (int)SW_STRIDE);
     CPE_CHECK_LAUNCH("clahe");
     int rc;
     if (side) {   // the 17 one-bit planes only need the CLAHE image
@@ -1973,13 +1989,11 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     // working rectangle for all 34 labelling passes = bounding box of the pixels brighter than the lowest threshold:
     // every brighter set and every hole of every binarisation lies inside it
     if ((rc = ccl_ctl(st, B.nrect, n, h, w, 2, s)) != CPE_OK) return rc;   // crect = the box k_clahe_apply accumulated
-    (void)hipMemsetAsync(B.sw, 0, (size_t)n * SW_STRIDE * sizeof(int), s);
     (void)hipMemsetAsync(B.touch, 0, total, s);
     const int swcap = std::max(32768, (int)std::min<long long>(1 << 20, (long long)N / 12));   // grid sizing only: entries one threshold may hold
     const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
-        CPE_KLAUNCH(k_bk_pass<false>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk, (int *)nullptr);
         CPE_KLAUNCH(k_bk_scan, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
         CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk, B.lab2);
         CPE_CHECK_LAUNCH("grey-level buckets");
