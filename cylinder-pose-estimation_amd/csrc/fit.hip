@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64) void k_select_triangulate(
     double *__restrict__ o_X, double *__restrict__ o_err, int *__restrict__ o_m,
     double *__restrict__ o_mean_err, int *__restrict__ o_flags)
 {
+    __builtin_amdgcn_s_setprio(3);   // one wavefront per frame beside wide kernels (see k_fit_cylinder)
     // per-point arrays: dynamic LDS (SEL_LDS_BYTES; more than the 64 KB a kernel may declare statically)
     double *sX = fit_dyn;                                                                   // [MAXP * 3]
     double *sErr = sX + MAXP * 3;                                                           // [MAXP]
@@ -912,6 +913,12 @@ __global__ __launch_bounds__(64) void k_fit_cylinder(const double *__restrict__ 
                                                      double *__restrict__ o_fvals, int *__restrict__ o_iters,
                                                      int *__restrict__ o_status)
 {
+    // One wavefront per frame, a chain of dependent f64 operations 200-300 simplex iterations long: beside the wide kernels of
+    // the other chunk in flight it waited its turn at every instruction (2.2 ms alone, 12 ms in the overlapped trace).  Its
+    // few waves ask for the highest issue priority of their SIMD; the wide kernels fill what is left (2.2 ms again in the
+    // overlapped trace; the bench rate does not move -- A/B on one box: 3166 / 3199 / 3198 with, 3175 / 3203 / 3182 without --,
+    // the latency of a chunk does).  The same on the other narrow kernels of the chain changed nothing measurable and was dropped.
+    __builtin_amdgcn_s_setprio(3);
     double *sP = fit_dyn, *sD = fit_dyn + MAXP * 3;   // dynamic LDS, FIT_LDS_BYTES
     __shared__ int sNb[20];
     const int f = blockIdx.x, lane = threadIdx.x;
