@@ -132,12 +132,17 @@ Layout make_layout(int n, int h, int w)
     return L;
 }
 
-__global__ void k_state_init(FrameState *st, int n)
+// per-frame state of a call, and the accumulators the three chains start from (one launch in front of the fork instead of a
+// reset kernel at the head of every chain)
+__global__ void k_state_init(FrameState *st, int n, unsigned long long *best, unsigned long long *best_s, int *nrect)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     FrameState z = {};
+    z.srect[0] = INT_MAX; z.srect[1] = INT_MAX; z.srect[2] = -1; z.srect[3] = -1;   // spot window: empty until k_spot_scan finds a tile
     st[f] = z;
+    if (best) { best[f] = 0; best_s[f] = 0; }                                      // largest-contour keys (region / spot)
+    if (nrect) { nrect[16 * f] = INT_MAX; nrect[16 * f + 1] = INT_MAX; nrect[16 * f + 2] = -1; nrect[16 * f + 3] = -1; }   // CLAHE's bounding box
 }
 
 __global__ void k_finish(const FrameState *st, int n, int *status, int *n_pts)
@@ -311,7 +316,7 @@ static int32_t detect_impl(const uint8_t *gray, const uint8_t *bgr, int32_t n, i
     auto enqueue = [&]() -> int {
         int rc;
         CPE_LAUNCH_BEGIN();
-        CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+        CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n, R.best, M.best_s, R.nrect);
         CPE_CHECK_LAUNCH("k_state_init");
         if (bgr) {      // BGR2GRAY (load_and_preprocess_image, mask_roi_around_center) and the L channel of BGR2LAB (detect_largest_blob)
             const size_t npx = (size_t)n * h * w;
@@ -471,7 +476,7 @@ extern "C" int32_t cpe_debug_external_components(const uint8_t *mask, int32_t n,
     int *roots = (int *)(base + L.off[P_ROOTS]);
     int rc;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n);
+    CPE_KLAUNCH(k_state_init, dim3((n + 63) / 64), dim3(64), 0, s, st, n, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr);
     CPE_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)n * sizeof(int), s));
     if ((rc = ccl_run(mask, n, h, w, 0, 0, 1, (int *)(base + L.off[P_LAB0]), roots, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 0)) != CPE_OK) return rc;
     const size_t bit_words = (size_t)n * h * bit_row_words(w), fl_words = (size_t)h * bit_row_words(w) / 2;

@@ -1199,13 +1199,6 @@ __global__ void k_masks_reset(FrameState *st, int n)
     if (S.status == CPE_ST_NO_REGION) { S.r0 = 0; S.spot[0] = S.spot[1] = S.spot[2] = S.spot[3] = 0; }
     else if (S.status == CPE_ST_OK && S.spot_fail) S.status = CPE_ST_NO_SPOT;
 }
-__global__ void k_spot_reset(int n, unsigned long long *best, FrameState *st)
-{
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    best[f] = 0;
-    st[f].srect[0] = INT_MAX; st[f].srect[1] = INT_MAX; st[f].srect[2] = -1; st[f].srect[3] = -1;   // empty until k_spot_scan finds a tile
-}
 
 inline unsigned grid1(size_t total) { return (unsigned)((total + 255) / 256); }
 
@@ -1331,7 +1324,7 @@ int spot_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, F
     const size_t total = (size_t)h * w * n;
     int rc;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_spot_reset, dim3((n + 63) / 64), dim3(64), 0, s, n, B.best_s, st);
+    // (B.best_s and st[].srect were reset by k_state_init)
     Taps t19 = {{1, 1, 3, 5, 10, 15, 20, 27, 30, 32, 30, 27, 20, 15, 10, 5, 3, 1, 1}, 9, 16};
     {
         const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;

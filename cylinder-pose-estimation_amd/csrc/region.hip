@@ -524,12 +524,6 @@ __device__ double wave_median(Get get, int n, int lane, double *s_buf, int *s_hi
 // registers, a 64-bucket histogram over [min, max] (monotone bucket map) finds the bucket that holds rank k, and only
 // that bucket's few members are compared with each other -- O(n) instead of the O(n^2) rank count of the general path.
 constexpr int MED_FAST = CH_DIRECT * CH_PTS;
-__global__ void k_sw_mark_holes(int *sw, int n)
-{
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    for (int t = 0; t < NTHR; t++) sw[(size_t)f * SW_STRIDE + SW_NA + t] = min(sw[(size_t)f * SW_STRIDE + SW_NB + t], MAXB);
-}
 
 // part 0: the blobs of the hole borders [0, NA), part 1: those of the bright components [NA, NB)
 __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ sw, BlobRec *__restrict__ blobs_all,
@@ -544,7 +538,9 @@ __global__ __launch_bounds__(64) void k_blob_median(int part, int *__restrict__ 
     __shared__ int s_cnt;
     const int f = blockIdx.y, slot = blockIdx.z, lane = threadIdx.x;
     int *S = sw + (size_t)f * SW_STRIDE;
-    const int nb = part ? min(S[SW_NB + slot], MAXB) : S[SW_NA + slot];
+    // part 0 runs before any bright component's blob is appended: the blobs listed so far are the hole borders' (SW_NA)
+    const int nb = min(S[SW_NB + slot], MAXB);
+    if (!part && blockIdx.x == 0 && lane == 0) S[SW_NA + slot] = nb;
     BlobRec *blobs = blobs_all + ((size_t)f * NTHR + slot) * MAXB;
     const int *blob_d = blob_d_all + ((size_t)f * NTHR + slot) * MAXB * 2;
     double *dists = dists_all + (size_t)f * NTHR * maxdf;
@@ -1085,6 +1081,16 @@ __global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img
     const size_t N = (size_t)h * w, f = blockIdx.y;
     const int t = threadIdx.x;
     const SwRect r = sw_rect(st, f);
+    int *S = sw + f * SW_STRIDE;
+    // first entry of every bucket = the sizes before it (counted by k_clahe_apply): every workgroup sums them for itself, the
+    // first one of a frame also leaves the table for the sweep kernels (k_bk_scan was a launch of its own for this)
+    __shared__ int s_off[NBK];
+    if (SCATTER && t < NBK) {
+        int off = 0;
+        for (int b = 1; b < t; b++) off += S[SW_BS + b];
+        s_off[t] = off;
+        if (blockIdx.x == 0 && t > 0) S[SW_BO + t] = off;
+    }
     {   // the workgroup's pixels lie in rows ya .. yb: nothing to do outside the working rectangle (three quarters of a frame)
         const size_t p0 = (size_t)blockIdx.x * BK_CHUNK;
         const int ya = (int)(p0 / w), yb = (int)(min(p0 + BK_CHUNK, N) - 1) / w;
@@ -1119,27 +1125,17 @@ __global__ __launch_bounds__(256) void k_bk_pass(const uint8_t *__restrict__ img
         if (l && SCATTER) lev[k] = l | (atomicAdd(&s_cnt[l], 1) << 8);   // rank inside this workgroup's share
     }
     __syncthreads();
-    int *S = sw + f * SW_STRIDE;
     if (!SCATTER) {
         if (t > 0 && t < NBK && s_cnt[t]) atomicAdd(&S[SW_BS + t], s_cnt[t]);
         return;
     }
-    if (t > 0 && t < NBK) s_base[t] = s_cnt[t] ? atomicAdd(&S[SW_BC + t], s_cnt[t]) : 0;
+    if (t > 0 && t < NBK) s_base[t] = s_cnt[t] ? s_off[t] + atomicAdd(&S[SW_BC + t], s_cnt[t]) : 0;   // the cursors start at 0 (memset)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < BK_CHUNK / 256; k++) {
         const int l = lev[k] & 255;
         if (l) bk[f * N + s_base[l] + (lev[k] >> 8)] = (int)((size_t)blockIdx.x * BK_CHUNK + k * 256 + t);
     }
-}
-
-__global__ void k_bk_scan(int *sw, int n)
-{
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    int *S = sw + (size_t)f * SW_STRIDE;
-    int off = 0;
-    for (int b = 1; b < NBK; b++) { S[SW_BO + b] = off; S[SW_BC + b] = off; off += S[SW_BS + b]; }
 }
 
 constexpr int SW_GRID = 96;       // workgroups per frame of the kernels that walk one bucket (fewer in large batches: 24 at 256 images)
@@ -1941,14 +1937,6 @@ __global__ void k_best_reset(int n, unsigned long long *best)
     if (f < n) best[f] = 0;
 }
 
-__global__ void k_region_reset(FrameState *st, int n, unsigned long long *best, int *nrect)
-{
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    nrect[16 * f] = INT_MAX; nrect[16 * f + 1] = INT_MAX; nrect[16 * f + 2] = -1; nrect[16 * f + 3] = -1;
-    st[f].n_groups = 0; st[f].n_kp = 0;
-    best[f] = 0;
-}
 
 }  // namespace
 
@@ -1970,7 +1958,7 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     if (clip > 0.0) { g.clipLimit = (int)(clip * tileTotal / 256); if (g.clipLimit < 1) g.clipLimit = 1; }
     g.lutScale = (float)255 / tileTotal;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best, B.nrect);
+    // (st[].n_groups / n_kp, B.best and the bounding-box accumulators B.nrect were reset by k_state_init)
     (void)hipMemsetAsync(B.hist, 0, (size_t)n * 16 * 256 * sizeof(unsigned int), s);
     const int strips = 8;
     CPE_KLAUNCH(k_clahe_hist, dim3(n * 16 * strips), dim3(256), 0, s, gray, n, h, w, g, strips, B.hist, lab_lut);
@@ -1994,7 +1982,6 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     const dim3 gpx((unsigned)((N + 255) / 256), n), glist(frame_waves(4 * n, 4, swcap / 256), n), gtrace(frame_waves(n * NTHR, 8, swcap / 64), n, NTHR), gtrace_h(frame_waves(n * NTHR, 4, swcap / 64), n, NTHR), gbk(std::min(SW_GRID, std::max(16, 6144 / n)), n);
     {
         const dim3 gchunk((unsigned)((N + BK_CHUNK - 1) / BK_CHUNK), n);
-        CPE_KLAUNCH(k_bk_scan, dim3((n + 63) / 64), dim3(64), 0, s, B.sw, n);
         CPE_KLAUNCH(k_bk_pass<true>, gchunk, dim3(256), 0, s, (const uint8_t *)B.cl, h, w, (const FrameState *)st, B.sw, B.bk, B.lab2);
         CPE_CHECK_LAUNCH("grey-level buckets");
     }
@@ -2033,7 +2020,6 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         // hole borders of all thresholds and their radii
         CPE_KLAUNCH(k_blob_trace<1>, gtrace_h, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
                     B.blob_d, B.dists, (const uint32_t *)B.bits, B.pool, B.blob_ch, B.maxch, B.maxdf);
-        CPE_KLAUNCH(k_sw_mark_holes, dim3((n + 63) / 64), dim3(64), 0, ds, B.sw, n);
         CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 16, 128), n, NTHR), dim3(64), 0, ds, 0, B.sw, B.blobs, (const int *)B.blob_d, B.dists,
                     (const uint32_t *)B.pool, (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
         if (side) (void)hipEventRecord(side->medians, ds);
@@ -2086,7 +2072,7 @@ int region_stage_plane(const uint8_t *gray, int n, int h, int w, const RegionBuf
     const size_t N = (size_t)h * w, total = N * n;
     int rc;
     CPE_LAUNCH_BEGIN();
-    CPE_KLAUNCH(k_region_reset, dim3((n + 63) / 64), dim3(64), 0, s, st, n, B.best, B.nrect);
+    // (st[].n_groups / n_kp, B.best and the bounding-box accumulators B.nrect were reset by k_state_init)
     (void)hipMemsetAsync(B.ext, 0, total, s);
     (void)hipMemsetAsync(B.mc, 0, total, s);
     EllipseSE se;
