@@ -104,7 +104,8 @@ inline unsigned frame_waves(int lists, int lo, int hi)
     return (unsigned)(v < lo ? lo : (v > hi ? hi : v));
 }
 // optional helper stream of the region stage: the hole borders are followed while the bright sweep runs
-struct RegionSide { hipStream_t s; hipEvent_t clahe_done, dark_done, traced, medians; };
+struct RegionSide { hipStream_t s; hipEvent_t clahe_done, dark_done, traced, medians;
+                    hipEvent_t joints_done = nullptr, spot_done = nullptr; };   // ends of the joints / spot chains (their label planes hold the tracers' tables afterwards)
 struct MaskBuffers {
     uint8_t *binary, *hmask, *vmask, *joints_mask, *tmpA, *tmpB, *g19, *cm, *mc, *roi_h, *roi_v, *base_h, *base_v, *exp_h,
         *exp_v, *touch;

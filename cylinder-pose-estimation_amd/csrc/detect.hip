@@ -109,19 +109,26 @@ Layout make_layout(int n, int h, int w)
     //   label scratch of the joints and spot chains (the latter again in the masks stage) | the lines stage's tables
     //   dark forest + its accumulator (dead when the dark sweep ends; the forest plane is used again for the region's own
     //   labelling after k_discs, the two as the expanded masks' label planes)              | blob records (hole borders .. k_blob_merge)
-    // Planes 0 .. P_G7 are readable after the call (cpe_detect_workspace_plane): nothing is ever written over them later.
+    // Planes 0 .. P_G7 are readable after the call (cpe_detect_workspace_plane): nothing is ever written over them later
+    // (mask_contour and blur7 share memory with the bright forest, which is dead before they are written).
     size_t o = 0;
     bool placed[P_COUNT] = {};
-    auto put = [&](std::initializer_list<int> a, std::initializer_list<int> b) {
-        size_t oa = o, ob = o;
+    auto put = [&](std::initializer_list<int> a, std::initializer_list<int> b, std::initializer_list<int> c = {}) {
+        size_t oa = o, ob = o, oc = o;
         for (int p : a) { L.off[p] = oa; oa += align_up(per[p] * (size_t)n, 256); placed[p] = true; }
         for (int p : b) { L.off[p] = ob; ob += align_up(per[p] * (size_t)n, 256); placed[p] = true; }
-        o = std::max(oa, ob);
+        for (int p : c) { L.off[p] = oc; oc += align_up(per[p] * (size_t)n, 256); placed[p] = true; }
+        o = std::max(oa, std::max(ob, oc));
     };
     for (int i = 0; i < P_COUNT; i++) L.bytes_per_frame[i] = per[i];
     put({P_DISTS, P_POOL}, {P_GROUPS});
-    put({P_LAB2, P_LAB3}, {P_ROI_H, P_ROI_V, P_BASE_H, P_BASE_V, P_EXP_H, P_EXP_V, P_TMPA, P_TMPB});
-    put({P_LABP, P_LABS}, {P_LINES, P_SUBPIX});
+    // (round 3) also on the masks side of the bright forest: the disc-union image, mask_contour and the 7x7 blur -- all first
+    // written after k_enclosed_all, the forest's last reader, on the same stream or behind the join.  The label planes of
+    // the joints and spot chains are only needed inside those chains' own labelling (roots-only passes): the border-chunk
+    // ids / distance offsets of the blob tracers live there between the hole traces and the medians -- the tracers' stream
+    // waits for the two chains (RegionSide::joints_done / spot_done) -- and the lines stage's tables after that.
+    put({P_LAB2, P_LAB3}, {P_ROI_H, P_ROI_V, P_BASE_H, P_BASE_V, P_EXP_H, P_EXP_V, P_TMPA, P_TMPB, P_EXT, P_MASK_CONTOUR, P_G7});
+    put({P_LABP, P_LABS}, {P_LINES, P_SUBPIX}, {P_BLOB_CH, P_BLOB_D});
     put({P_LAB0, P_LAB1}, {P_BLOBS});
     for (int i = 0; i < P_COUNT; i++) {
         if (placed[i]) continue;
@@ -334,12 +341,14 @@ static int32_t detect_impl(const uint8_t *gray, const uint8_t *bgr, int32_t n, i
         if ((rc = cpe_preprocess_batch(gray, n, h, w, M.binary, (void *)s1)) != CPE_OK) return rc;
         if ((rc = joints_mask_stage(n, h, w, M, st, s1)) != CPE_OK) return rc;
         if ((rc = spot_stage(gray, n, h, w, M, st, s2, planar)) != CPE_OK) return rc;
-        RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d};
+        if (X.ok) {   // ends of the joints and the spot chain (nothing more is enqueued on s1 / s2 before the join below)
+            CPE_CHECK_HIP(hipEventRecord(X.join1, X.s1));
+            CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
+        }
+        RegionSide rside = {X.s3, X.e3a, X.e3b, X.e3c, X.e3d, X.join1, X.join2};
         if (planar) { if ((rc = region_stage_plane(gray, n, h, w, R, st, s)) != CPE_OK) return rc; }
         else if ((rc = region_stage(gray, n, h, w, 4.5, R, st, s, X.ok ? &rside : nullptr, lplane)) != CPE_OK) return rc;
         if (X.ok) {
-            CPE_CHECK_HIP(hipEventRecord(X.join1, X.s1));
-            CPE_CHECK_HIP(hipEventRecord(X.join2, X.s2));
             CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join1, 0));
             CPE_CHECK_HIP(hipStreamWaitEvent(s, X.join2, 0));
             forked = false;

@@ -2016,6 +2016,10 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
         CPE_CHECK_LAUNCH("blob sweep (dark)");
     }
     CPE_KLAUNCH(k_sw_snap, dim3(sw_grid(n_grid, g_list)), dim3(256), 0, ds, nx, g_list, B.hl, B.sw, (int)SW_NH, NTHR - 1, h, w, (const int *)B.cnt, B.tl, st);
+    if (side && side->joints_done) {   // blob_ch / blob_d share memory with the label planes of the joints and spot chains
+        (void)hipStreamWaitEvent(ds, side->joints_done, 0);
+        (void)hipStreamWaitEvent(ds, side->spot_done, 0);
+    }
     {
         // hole borders of all thresholds and their radii
         CPE_KLAUNCH(k_blob_trace<1>, gtrace_h, dim3(64), 0, ds, (const uint8_t *)B.cl, h, w, (const int2 *)B.tl, (int)SW_NT, st, B.sw, B.blobs,
