@@ -338,7 +338,7 @@ def run_rank(args):
     scaling = args.scaling or ('strong' if world > 1 else 'weak')
     auto_chunk = args.chunk <= 0
     if auto_chunk:
-        args.chunk = 228 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~195 MB (1920x1200) / ~635 MB (4K) of workspace
+        args.chunk = 228 if H * W <= 1920 * 1200 else 56   # x lanes x 2 images x ~170 MB (1920x1200) / ~582 MB (4K) of workspace
     if scaling == 'strong':
         total = args.frames
         lo, hi = D.shard_range(total, rank, world)
@@ -347,7 +347,7 @@ def run_rank(args):
         lo, hi = rank * args.frames, (rank + 1) * args.frames
     F = hi - lo
     if auto_chunk and F > 0:
-        # equal chunks of at most 228 frames (round 3, workspace 195 MB per image: 208-240 frames per call is the sweet spot --
+        # equal chunks of at most 228 frames (round 3, workspace 170-195 MB per image: 208-240 frames per call is the sweet spot --
         # 4096 frames as chunks of 171: 2767 frames/s, 208: 2854, 224: 2867, 240: 2865, 300: 2753; calls of exactly 256 or 512
         # images are 6-10 % slower than their neighbours (128: 2478, 256: 2712) -- not an alignment effect: skewing the plane
         # offsets and the lanes' workspaces changed nothing; an odd number of chunks on two lanes costs nothing);

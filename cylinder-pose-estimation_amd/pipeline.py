@@ -3,7 +3,7 @@
 
 This is the loop body of exp_gridDetection.m:55-81 (makePyGridPts L/R, then fitSingleCylinder per frame)
 turned into batched kernel launches; frames are processed in chunks so that the detect workspace stays
-bounded (about 195 MB per 1920x1200 image: DESIGN.md section 3)."""
+bounded (about 170 MB per 1920x1200 image: DESIGN.md section 3)."""
 import torch
 
 from . import api, fit
