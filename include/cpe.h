@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CPE_VERSION 100
+#define CPE_VERSION 103   /* 100 + round: exports are only ever added (103: cpe_detect_grid_bgr_batch_ex, cpe_detect_constants) */
 
 #if defined(__GNUC__)
 #define CPE_API __attribute__((visibility("default")))
