@@ -74,7 +74,7 @@ Layout make_layout(int n, int h, int w)
     per[P_LUT] = 16 * 256;
     per[P_BLOBS] = (size_t)17 * MAXB * sizeof(BlobRec);
     per[P_BLOB_D] = (size_t)17 * MAXB * 2 * sizeof(int);
-    per[P_ORDER] = (size_t)MAXB * sizeof(int);
+    per[P_ORDER] = (size_t)2 * MAXB * sizeof(int);   // + scratch of k_blob_merge's bucketed ranking
     per[P_DISTS] = (size_t)17 * region_maxdf(h, w) * sizeof(double);
     per[P_POOL] = (size_t)17 * region_maxch(h, w) * 128;
     per[P_BLOB_CH] = (size_t)17 * MAXB * 16 * sizeof(unsigned short);

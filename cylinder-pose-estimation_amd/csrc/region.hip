@@ -679,6 +679,7 @@ constexpr int MG_NT = 256;     // threads of k_blob_merge (4 wavefronts: cell ra
 constexpr int MG_CELLS = 1024; // grid cells (the cell edge doubles until the frame fits: 64 px at 1920 x 1200, 128 px at 3840 x 2160)
 constexpr int MG_LCAP = 24;    // centres per staged list
 constexpr int MG_STAGE = MG_LCAP - 4;
+constexpr int MG_RANK_DIRECT = 4096, MG_RANK_BUCKETS = 4096;   // blobs of a threshold ranked all-pairs in LDS up to this many; key buckets beyond
 __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ st, const int *__restrict__ sw,
                                                     const BlobRec *__restrict__ blobs_all, int *__restrict__ order,
                                                     Group *__restrict__ groups, int always_replay, double *__restrict__ gmid_all,
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     __shared__ int s_ng, s_serial, s_adv, s_maxn;
     const int f = blockIdx.x, t = threadIdx.x, lane = t & 63;
     FrameState &S = st[f];
-    int *ord = order + (size_t)f * MAXB;
+    int *ord = order + (size_t)f * 2 * MAXB;   // [0, MAXB): blob indices in cv2.findContours order; [MAXB, 2 MAXB): scratch of the bucketed ranking
     Group *G = groups + (size_t)f * MAXG;
     double *gm = gmid_all + (size_t)f * (MAXG - MAXG_LDS) * 4 - (size_t)MAXG_LDS * 4;   // gm[4 j ..] = x, y, r, next for j >= MAXG_LDS
     // HBM entries are written by other wavefronts of this workgroup between barriers: read past the vector L1
@@ -754,16 +755,52 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
     for (int thr = 0; thr < NTHR; thr++) {
         const int nb = min(sw[(size_t)f * SW_STRIDE + SW_NB + thr], MAXB);
         const BlobRec *B = blobs_all + ((size_t)f * NTHR + thr) * MAXB;
-        {   // rank by key (keys are distinct); the keys are staged in the list buffer, which is idle between thresholds
+        if (nb <= MG_RANK_DIRECT && !(always_replay & 2)) {
+            // rank by key (keys are distinct); the keys are staged in the list buffer, which is idle between thresholds
             int *keys = reinterpret_cast<int *>(&pl[0][0]);
-            const bool staged = nb <= (int)(sizeof(pl) / sizeof(int));   // else: straight from the blob records
-            if (staged) for (int i = t; i < nb; i += MG_NT) keys[i] = B[i].key;
+            for (int i = t; i < nb; i += MG_NT) keys[i] = B[i].key;
             __syncthreads();
             for (int i = t; i < nb; i += MG_NT) {
-                const int ki = staged ? keys[i] : B[i].key;
+                const int ki = keys[i];
                 int rank = 0;
-                if (staged) { for (int j = 0; j < nb; j++) rank += (keys[j] > ki) ? 1 : 0; }
-                else { for (int j = 0; j < nb; j++) rank += (B[j].key > ki) ? 1 : 0; }
+                for (int j = 0; j < nb; j++) rank += (keys[j] > ki) ? 1 : 0;
+                ord[rank] = i;
+            }
+        } else {
+            // a threshold of a noisy frame (up to 32768 blobs: the all-pairs count was 40 ms of key reads per such threshold):
+            // bucket the keys by value (they are pixel indices), count, prefix from the top bucket down, scatter the blob
+            // indices bucket by bucket into the scratch half of `order`, and rank every key among its bucket's few members
+            int *cntb = reinterpret_cast<int *>(&pl[0][0]), *curb = cntb + MG_RANK_BUCKETS;
+            int *scr = ord + MAXB;
+            const int bw = (int)(((size_t)h * w + MG_RANK_BUCKETS - 1) / MG_RANK_BUCKETS);
+            for (int b = t; b < MG_RANK_BUCKETS; b += MG_NT) cntb[b] = 0;
+            __syncthreads();
+            for (int i = t; i < nb; i += MG_NT) atomicAdd(&cntb[min(B[i].key / bw, MG_RANK_BUCKETS - 1)], 1);
+            __syncthreads();
+            {   // curb[b] = number of keys in the buckets above b (the rank of a bucket's largest key): a thread sums its run
+                // of buckets from the top down, the runs are chained through s_mod (64 ints, idle here) wave by wave
+                constexpr int PER = MG_RANK_BUCKETS / MG_NT;
+                const int b_hi = MG_RANK_BUCKETS - 1 - PER * t;          // this thread's buckets: b_hi, b_hi - 1, ..., b_hi - PER + 1
+                int sum = 0;
+                for (int k = 0; k < PER; k++) sum += cntb[b_hi - k];
+                int incl = sum;
+                for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+                if (lane == 63) s_mod[t >> 6] = incl;
+                __syncthreads();
+                int base = incl - sum;
+                for (int k = 0; k < (t >> 6); k++) base += s_mod[k];
+                for (int k = 0; k < PER; k++) { curb[b_hi - k] = base; base += cntb[b_hi - k]; }
+            }
+            __syncthreads();
+            for (int i = t; i < nb; i += MG_NT) scr[atomicAdd(&curb[min(B[i].key / bw, MG_RANK_BUCKETS - 1)], 1)] = i;
+            __threadfence_block();
+            __syncthreads();
+            for (int i = t; i < nb; i += MG_NT) {
+                const int ki = B[i].key, b = min(ki / bw, MG_RANK_BUCKETS - 1);
+                const int end = curb[b], start = end - cntb[b];          // the cursor now stands behind the bucket's last entry
+                int rank = start;
+                for (int p = start; p < end; p++)
+                    rank += (B[__hip_atomic_load(scr + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].key > ki) ? 1 : 0;
                 ord[rank] = i;
             }
         }
@@ -870,7 +907,7 @@ __global__ __launch_bounds__(MG_NT) void k_blob_merge(FrameState *__restrict__ s
             if (t < 64) {
                 const unsigned long long bb = __ballot(s_bad[lane] != 0);
                 const int clean = bb ? __ffsll((long long)bb) - 1 : qn;   // >= 1: lane 0 has no earlier blob
-                const bool serial = always_replay || (clean < qn && clean < 8);
+                const bool serial = (always_replay & 1) || (clean < qn && clean < 8);
                 if (!serial) {
                     const bool mine = lane < clean;
                     int link_g = -1, link_c = 0, old_c = -1;   // grid: group to (re)link into cell link_c; old_c >= 0: it leaves that cell
@@ -2049,10 +2086,11 @@ int region_stage(const uint8_t *gray, int n, int h, int w, double clip, const Re
     CPE_KLAUNCH(k_blob_median, dim3(frame_waves(n * NTHR, 8, 32), n, NTHR), dim3(64), 0, s, 1, B.sw, B.blobs, (const int *)B.blob_d, B.dists, (const uint32_t *)B.pool,
                 (const unsigned short *)B.blob_ch, st, B.maxch, B.maxdf);
     {
-        // CPE_MERGE_REPLAY=1 (tests): every batch takes the in-order replay path instead of the lane-per-blob one
+        // CPE_MERGE_REPLAY (tests): bit 0: every batch takes the in-order replay path instead of the lane-per-blob one;
+        // bit 1: every threshold is ranked by the bucketed method of the noisy frames
         const char *e = getenv("CPE_MERGE_REPLAY");
         CPE_KLAUNCH(k_blob_merge, dim3(n), dim3(MG_NT), 0, s, st, (const int *)B.sw, (const BlobRec *)B.blobs, B.order, B.groups,
-                    (e && e[0] == '1') ? 1 : 0, B.gmid, h, w);
+                    e ? atoi(e) & 3 : 0, B.gmid, h, w);
     }
     CPE_CHECK_LAUNCH("blob merge");
     (void)hipMemsetAsync(B.ext, 0, total, s);

@@ -237,7 +237,8 @@ def test_subpixel_mode_matches_oracle(cpe, orc, gpu, h, w, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('env', [{'CPE_SERIAL': '1'}, {'CPE_MERGE_REPLAY': '1'}, {'CPE_SERIAL': '1', 'CPE_MERGE_REPLAY': '1'}])
+@pytest.mark.parametrize('env', [{'CPE_SERIAL': '1'}, {'CPE_MERGE_REPLAY': '1'}, {'CPE_SERIAL': '1', 'CPE_MERGE_REPLAY': '1'},
+                                 {'CPE_MERGE_REPLAY': '2'}, {'CPE_MERGE_REPLAY': '3'}])   # 2: bucketed ranking of every threshold's blobs
 def test_execution_variants_give_identical_results(cpe, orc, gpu, env, monkeypatch):
     """stream overlap on / off and the two paths of the batched blob grouping (lane-per-blob vs in-order replay) are
     scheduling choices only: tables, statuses and the order-dependent intermediates must not change by a bit"""
