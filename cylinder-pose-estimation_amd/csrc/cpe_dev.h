@@ -115,6 +115,7 @@ struct MaskBuffers {
     uint32_t *bits;
     unsigned long long *best, *best_s;
     unsigned long long *fl_j;                 // joints chain: [n][h * ceil(w/64)] background masks, then the same of outer background
+    uint32_t *jbits;                          // one-bit plane of the joints mask (build_bitplanes layout, one plane per frame)
     SegRec *segs;
 };
 

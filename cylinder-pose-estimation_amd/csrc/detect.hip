@@ -93,7 +93,7 @@ Layout make_layout(int n, int h, int w)
     per[P_ROOTSP] = (size_t)MAXROOTS * sizeof(int);
     per[P_ROOTSS] = (size_t)MAXROOTS * sizeof(int);
     per[P_BEST2] = sizeof(unsigned long long);
-    per[P_HPAR] = 16;      // (unused: the merge history lives in the bright forest's nodes)
+    per[P_HPAR] = (size_t)h * bit_row_words(w) * sizeof(uint32_t);   // (slot re-used) one-bit plane of the joints mask, written by k_open20_joints
     per[P_HTIME] = 16;
     per[P_GMID] = (size_t)(MAXG - MAXG_LDS) * 4 * sizeof(double);   // x, y, r, next group in the grid cell
     per[P_FLJ] = (size_t)2 * h * ((w + 63) / 64) * sizeof(unsigned long long);   // joints chain: background / outer-background bit masks
@@ -310,7 +310,7 @@ static int32_t detect_impl(const uint8_t *gray, const uint8_t *bgr, int32_t n, i
     M.best = R.best; M.segs = PL(SegRec, P_SEGS);
     M.lab_p = PL(int, P_LABP); M.lab_s = PL(int, P_LABS); M.roots_p = PL(int, P_ROOTSP); M.roots_s = PL(int, P_ROOTSS);
     M.best_s = PL(unsigned long long, P_BEST2);
-    M.fl_j = PL(unsigned long long, P_FLJ);
+    M.fl_j = PL(unsigned long long, P_FLJ); M.jbits = PL(uint32_t, P_HPAR);
     // three chains that only meet in masks_stage: ridge mask -> line masks -> joints (stream 1), saturated spot
     // (stream 2), region (the caller's stream).  The side chains are mostly ALU / latency bound and fill the CUs the
     // region stage's serial kernels leave idle.  The helper streams and their events are per device and shared by all

@@ -72,8 +72,10 @@ constexpr int OB_AP = 20;
 template <int R>
 __global__ __launch_bounds__(256) void k_open20_joints(const uint8_t *__restrict__ bin, int h, int w, int bands,
                                                        uint8_t *__restrict__ hm, uint8_t *__restrict__ vm,
-                                                       uint8_t *__restrict__ jm)
+                                                       uint8_t *__restrict__ jm, uint32_t *__restrict__ jbits)
 {
+    // jbits: the joints mask once more as a one-bit plane (the words are in LDS anyway): its labelling, its RETR_EXTERNAL
+    // flood and the border tracer of the joint centroids read an eighth of the bytes
     constexpr int ROWS = R + 2 * OB_AP;
     extern __shared__ unsigned long long s_ob[];
     const int WW = (w + 63) >> 6;
@@ -170,6 +172,24 @@ __global__ __launch_bounds__(256) void k_open20_joints(const uint8_t *__restrict
                     jm[o + b] = (((hb & vb) >> b) & 1u) ? 255 : 0;
                 }
             }
+        }
+        // pixel x is bit x + 32 of its plane row: word 0 and the words behind the last pixel are zero
+        const int ws = bit_row_words(w);
+        for (int i = t; i < R * (WW + 1); i += 256) {
+            const int tr = i / (WW + 1), j = i - tr * (WW + 1);
+            const int y = y0 + tr;
+            if (y >= h) continue;
+            uint32_t *row = jbits + ((size_t)f * h + y) * ws;
+            if (j == WW) {
+                row[0] = 0;
+                for (int k = 1 + 2 * WW; k < ws; k++) row[k] = 0;
+                continue;
+            }
+            const size_t wi = (size_t)tr * WW + j;
+            unsigned long long m = hbuf[wi] & (buf0[wi] | ((tr + 12 < ROWS) ? buf1[wi + (size_t)12 * WW] : 0ull));
+            if (64 * j + 64 > w) m &= (1ull << (w - 64 * j)) - 1ull;      // columns past the end of the row
+            row[1 + 2 * j] = (uint32_t)m;
+            row[2 + 2 * j] = (uint32_t)(m >> 32);
         }
     }
 }
@@ -320,19 +340,20 @@ __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m,
 }
 
 // ---- joints: polygon-moment centroids inside the region rectangle, in cv2.findContours order ----------
-__global__ __launch_bounds__(64) void k_joint_centroids(const uint8_t *__restrict__ jm, int h, int w,
+__global__ __launch_bounds__(64) void k_joint_centroids(const uint32_t *__restrict__ jbits, int h, int w,
                                                         const int *__restrict__ roots, FrameState *__restrict__ st,
                                                         int *__restrict__ jtmp /* n*MAXJ*3 */,
                                                         const unsigned long long *__restrict__ outside, size_t plane_words)
 {
+    __shared__ unsigned long long s_win[BW_ROWS * 64];   // the tracer's bit window, one column per lane (cpe_dev.h: BitWin)
     const int f = blockIdx.y;
     if (st[f].status != CPE_ST_OK) return;
-    const size_t N = (size_t)h * w;
     const int ncomp = min(st[f].n_roots_p, MAXROOTS);
     for (int k = blockIdx.x * 64 + threadIdx.x; k < ncomp; k += gridDim.x * 64) {
         const int root = roots[(size_t)f * MAXROOTS + k];
         if (!comp_is_external(outside + f * plane_words, w, root, 0)) continue;   // RETR_EXTERNAL (:1817): inside a hole of another blob
-        MaskPred nz{jm + f * N, w, h};
+        const int ws = bit_row_words(w);
+        BitWin nz{jbits + (size_t)f * h * ws, ws, h, s_win + threadIdx.x};
         StatVisitor sv;
         if (!trace_border(nz, root % w, root / w, false, sv, 4 * (w + h) + 65536)) { set_overflow(st[f], OVF_TRACE); continue; }
         sv.finish();
@@ -1302,20 +1323,22 @@ int joints_mask_stage(int n, int h, int w, const MaskBuffers &B, FrameState *st,
         if (lds64 <= 96 * 1024) {
             const int bands = (h + 63) / 64;
             CPE_KLAUNCH(k_open20_joints<64>, dim3((unsigned)(n * bands)), dim3(256), lds64, s, (const uint8_t *)B.binary, h, w, bands,
-                        B.hmask, B.vmask, B.joints_mask);
+                        B.hmask, B.vmask, B.joints_mask, B.jbits);
         } else {
             CPE_CHECK_ARG(lds32 <= 160 * 1024, "joints_mask_stage: frame too wide (%d columns)", w);
             const int bands = (h + 31) / 32;
             CPE_KLAUNCH(k_open20_joints<32>, dim3((unsigned)(n * bands)), dim3(256), lds32, s, (const uint8_t *)B.binary, h, w, bands,
-                        B.hmask, B.vmask, B.joints_mask);
+                        B.hmask, B.vmask, B.joints_mask, B.jbits);
         }
     }
     CPE_CHECK_LAUNCH("joints_mask_stage");
     int rc;
-    if ((rc = ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab_p, B.roots_p, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 1)) != CPE_OK) return rc;
+    rc = ccl_roots_bits(B.jbits, n, h, w, B.lab_p, B.roots_p, 0, st, s, 1);          // labelling on the one-bit plane
+    if (rc == CPE_ERR_ARG) rc = ccl_run(B.joints_mask, n, h, w, 0, 0, 1, B.lab_p, B.roots_p, false, nullptr, 0, nullptr, 0, nullptr, st, s, 1, 1, 1);
+    if (rc != CPE_OK) return rc;
     // RETR_EXTERNAL (:1817): outer background of the joints mask (whole frame), on this chain, beside the region stage
     const size_t fl_words = (size_t)h * ((w + 63) / 64);
-    return outside_flood(B.joints_mask, n, h, w, st, 0, B.fl_j, B.fl_j + (size_t)n * fl_words, fl_words, s);
+    return outside_flood(B.joints_mask, n, h, w, st, 0, B.fl_j, B.fl_j + (size_t)n * fl_words, fl_words, s, B.jbits);
 }
 
 // a-5 head: saturated spot -> circle_mask, r0 (depends on the grey frame only: own stream)
@@ -1365,7 +1388,7 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
     if (jside) { (void)hipEventRecord(side->clahe_done, s); (void)hipStreamWaitEvent(sj, side->clahe_done, 0); }
     {
         hipStream_t q = jside ? sj : s;
-        CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, q, B.joints_mask, h, w, B.roots_p, st, B.jtmp,
+        CPE_KLAUNCH(k_joint_centroids, dim3(frame_waves(n, 16, MAXROOTS / 64), n), dim3(64), 0, q, (const uint32_t *)B.jbits, h, w, B.roots_p, st, B.jtmp,
                     (const unsigned long long *)(B.fl_j + (size_t)n * h * ((w + 63) / 64)), (size_t)h * ((w + 63) / 64));
         CPE_KLAUNCH(k_joint_sort, dim3(n), dim3(256), 0, q, st, B.jtmp, B.joints);
     }
