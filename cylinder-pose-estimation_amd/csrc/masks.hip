@@ -247,8 +247,10 @@ constexpr int RB_R = 64, RB_AP = 4, RB_ROWS = RB_R + 2 * RB_AP;
 __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m, const uint8_t *__restrict__ cm,
                                                   const uint8_t *__restrict__ mc, int h, int w, int bands,
                                                   const FrameState *__restrict__ st, uint8_t *__restrict__ roi,
-                                                  uint8_t *__restrict__ base)
+                                                  uint8_t *__restrict__ base, uint32_t *__restrict__ bbits)
 {
+    // bbits: `base` once more as a one-bit plane (build_bitplanes layout, one plane per frame): the words are in LDS anyway,
+    // and the fragments' labelling, flood and border tracer read the plane
     extern __shared__ unsigned long long s_rb[];
     const int WW = (w + 63) >> 6;
     unsigned long long *buf0 = s_rb, *buf1 = s_rb + (size_t)RB_ROWS * WW;
@@ -271,6 +273,11 @@ __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m,
             if (y >= h || x0 >= w) continue;
             const size_t o = f * N + (size_t)y * w + x0;
             store8(roi, o, x0, 0u); store8(base, o, x0, 0u);
+        }
+        const int ws = bit_row_words(w);
+        for (int i = t; i < RB_R * ws; i += 256) {
+            const int tr = i / ws, y = y0 + tr;
+            if (y < h) bbits[((size_t)f * h + y) * ws + (i - tr * ws)] = 0u;
         }
         return;
     }
@@ -337,6 +344,23 @@ __global__ __launch_bounds__(256) void k_roi_base(const uint8_t *__restrict__ m,
     pass(buf0, buf1, true);    // dilate
     pass(buf1, buf0, false);   // erode -> base
     emit(buf0, base);
+    {   // pixel x is bit x + 32 of its plane row: word 0 and the words behind the last pixel are zero
+        const int ws = bit_row_words(w);
+        for (int i = t; i < RB_R * (WW + 1); i += 256) {
+            const int tr = i / (WW + 1), j = i - tr * (WW + 1);
+            const int y = y0 + tr;
+            if (y >= h) continue;
+            uint32_t *row = bbits + ((size_t)f * h + y) * ws;
+            if (j == WW) {
+                row[0] = 0;
+                for (int k = 1 + 2 * WW; k < ws; k++) row[k] = 0;
+                continue;
+            }
+            const unsigned long long m64 = buf0[(size_t)(tr + RB_AP) * WW + j];     // (columns past the row's end are 0: row_valid_word)
+            row[1 + 2 * j] = (uint32_t)m64;
+            row[2 + 2 * j] = (uint32_t)(m64 >> 32);
+        }
+    }
 }
 
 // ---- joints: polygon-moment centroids inside the region rectangle, in cv2.findContours order ----------
@@ -1412,8 +1436,7 @@ int masks_stage(const uint8_t *gray, int n, int h, int w, const MaskBuffers &B, 
         SegRec *segs = B.segs + (size_t)which * n * MAXSEG;
         // roi = open3x3(mask & circle_mask & mask_contour), base = close3x3(roi)
         CPE_KLAUNCH(k_roi_base, dim3((unsigned)(n * rb_bands)), dim3(256), rb_lds, q, lm, (const uint8_t *)B.cm, (const uint8_t *)B.mc,
-                    h, w, rb_bands, (const FrameState *)st, roi, base);
-        if ((rc = build_bitplanes(base, n, h, w, 0, 0, 1, bits, q)) != CPE_OK) return rc;
+                    h, w, rb_bands, (const FrameState *)st, roi, base, bits);   // + base's one-bit plane
         rc = ccl_roots_bits(bits, n, h, w, lab, roots, 2, st, q, sel);         // labelling on the one-bit plane
         if (rc == CPE_ERR_ARG) rc = ccl_run(base, n, h, w, 0, 0, 1, lab, roots, false, nullptr, 0, nullptr, 2, nullptr, st, q, 1, 1, sel);
         if (rc != CPE_OK) return rc;
