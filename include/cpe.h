@@ -14,9 +14,11 @@
  *   - extern "C", plain pointers and sizes; every buffer is caller-owned DEVICE memory
  *     (e.g. torch tensors, pass tensor.data_ptr()); no allocation inside, scratch comes from
  *     the caller-supplied workspace.  Process state: the thread-local error string, the optional profiling timers,
- *     and per device three helper streams with their events (cpe_detect_grid_batch* overlaps independent chains
- *     on them; calls on one device are serialised over their enqueue by a per-device mutex, so the library is
- *     thread-safe; CPE_SERIAL=1 in the environment keeps everything on the caller's stream).
+ *     and sets of three helper streams with their events, one set per (device, caller stream) for up to four caller
+ *     streams per device (further ones share the last set): cpe_detect_grid_batch* overlaps the independent chains of a
+ *     call on them, so calls on different caller streams do not serialise each other; the enqueue of a call (host side,
+ *     fork to join) holds its set's mutex, so the library is thread-safe; CPE_SERIAL=1 in the environment keeps
+ *     everything on the caller's stream.
  *   - every call is asynchronous on `stream` (a hipStream_t, passed as void*; NULL = default
  *     stream) and graph-capturable; no host synchronisation inside.
  *   - return value: 0 ok, <0 argument / launch error (text via cpe_last_error_string()).
